@@ -1,0 +1,168 @@
+/* thr_hip.h -- C ABI of the MI355X-native retrieval hot path (libthr_hip.so).
+ *
+ * The reference (matheusfalcaopinto/triple-hybrid-rag) has no FFI layer: its
+ * scorers run inside PostgreSQL / PuppyGraph / remote model servers and are
+ * reached from Python over HTTP.  Each entry point
+ * below replaces one of those out-of-process scorers; the reference call site
+ * it stands behind is cited (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory (hipMalloc'd or a
+ *     PyTorch-ROCm tensor's data_ptr) unless the name starts with ``h_``;
+ *   - all work is enqueued on ``stream`` (a hipStream_t passed as void*; 0 =
+ *     the null stream); nothing synchronises, allocates or frees;
+ *   - return 0 on success, a negative THR_ERR_* for argument/capacity errors,
+ *     or a positive hipError_t if a launch failed;
+ *   - doc / chunk / entity ids are indices into the caller's arrays; outputs
+ *     add ``id_base`` so a document-sharded index reports global ids;
+ *   - total order of every ranked output: (score descending, id ascending).
+ */
+#ifndef THR_HIP_H
+#define THR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THR_ABI_VERSION 1
+
+typedef void *thr_stream_t;
+
+enum {
+    THR_OK = 0,
+    THR_ERR_INVALID = -1,     /* null pointer / negative size / k out of range */
+    THR_ERR_UNSUPPORTED = -2, /* shape the kernels are not built for */
+    THR_ERR_WORKSPACE = -3,   /* workspace smaller than thr_*_workspace_bytes */
+    THR_ERR_CAPACITY = -4     /* a fixed on-chip capacity would be exceeded */
+};
+
+/* per-query status bits written by thr_dense_topk */
+#define THR_FLAG_CERTIFIED 1u /* top-k proven exact by the fp32-error certificate */
+#define THR_FLAG_OVERFLOW 2u  /* candidate buffer overflowed (never certified)    */
+#define THR_FLAG_EXACT 4u     /* produced by the exhaustive float64 path          */
+
+#define THR_DENSE_MAX_K 256   /* k and k' (shortlist) upper bound */
+#define THR_BM25_MAX_TERMS 32
+#define THR_GRAPH_MAX_SEEDS 16
+#define THR_RRF_MAX_PER_CHANNEL 128
+#define THR_TOPK_MAX 128      /* bm25 / graph k upper bound */
+
+int thr_abi_version(void);
+const char *thr_error_string(int code);
+/* CUs, HBM bytes and gcnArchName of the current device (host-side query). */
+int thr_device_info(int *h_compute_units, int64_t *h_hbm_bytes, char *h_arch, int h_arch_len);
+
+/* a1  query-embedding post-processing: prefix-truncate to ``store_dim`` and
+ * L2-normalise in float32, zero rows stay zero.
+ * Replaces truncate_matryoshka/normalize_l2, src/voice_agent/rag2/embedder.py:31-68
+ * (the model forward that produces ``full`` is an external server). */
+int thr_embed_postproc(const float *full, int n, int full_dim, int store_dim,
+                       float *out /* [n, min(full_dim,store_dim)] */, thr_stream_t stream);
+
+/* Index build helper: ||d|| per row as sqrt of the sequential float64 sum of
+ * squares, and float32 1/||d|| (0 for a zero row = "embedding IS NULL",
+ * database/migrations/20260114_rag2_schema.sql:404). */
+int thr_doc_norms(const float *docs, int64_t n_docs, int dim, double *dnorm, float *inv_norm,
+                  thr_stream_t stream);
+
+/* a2  dense channel: exact brute-force cosine top-k of ``n_queries`` queries
+ * over an HBM-resident float32 corpus [n_docs, dim] (dim % 256 == 0).
+ * Replaces SQL rag2_semantic_search (`1 - (embedding_1024 <=> q)` ORDER BY
+ * distance LIMIT k), database/migrations/20260114_rag2_schema.sql:377-410,
+ * called from src/voice_agent/rag2/retrieval.py:304-312, and the client-side
+ * np.dot fallback src/voice_agent/retrieval/hybrid_search.py:285-316.
+ *
+ * Pass 1 streams the corpus once per tile of queries in float32 and keeps a
+ * shortlist of k' = ``kprime`` rows per query; pass 2 rescans the shortlist in
+ * float64 (sequential accumulation, the oracle's contract) and orders it.
+ * out_flags[q] has THR_FLAG_CERTIFIED when the float32 error bound proves the
+ * top-k exact; otherwise call thr_dense_topk_exact for that query.
+ * Outputs are padded with (-inf, -1) beyond out_counts[q]. */
+size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queries, int kprime);
+int thr_dense_topk(const float *docs, const double *dnorm, const float *inv_norm, int64_t n_docs,
+                   int dim, int64_t id_base, const float *queries, int n_queries, int k,
+                   int kprime, double *out_scores /* [nq,k] */, int64_t *out_ids /* [nq,k] */,
+                   int32_t *out_counts /* [nq] */, uint32_t *out_flags /* [nq] */,
+                   void *workspace, size_t workspace_bytes, thr_stream_t stream);
+
+/* Exhaustive float64 path (every row scored with the oracle's arithmetic);
+ * used for queries thr_dense_topk could not certify (massive ties). */
+size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries);
+int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs, int dim,
+                         int64_t id_base, const float *queries, int n_queries, int k,
+                         double *out_scores, int64_t *out_ids, int32_t *out_counts,
+                         uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                         thr_stream_t stream);
+
+/* Timing/roofline probe: ONLY the streaming pass-1 kernel of thr_dense_topk
+ * (threshold filter against ``tau``), for ``n_tiles`` query tiles. */
+int thr_dense_scan_probe(const float *docs, const float *inv_norm, int64_t n_docs, int dim,
+                         const float *queries, int n_queries, void *workspace,
+                         size_t workspace_bytes, thr_stream_t stream);
+
+/* a3  lexical channel: Okapi BM25 (k1, b) top-k over a CSR inverted index,
+ * OR semantics, float64 accumulation in query-term order.
+ * Stands where SQL rag2_lexical_search (ts_rank_cd ... ORDER BY rank DESC
+ * LIMIT k) is called, rag2_schema.sql:341-374 / retrieval.py:282-290; the
+ * north-star mandates BM25 in its place.  ``query_terms`` is [nq, max_terms]
+ * term ids, negative = padding.  idf[] and avgdl are corpus-GLOBAL. */
+int thr_bm25_topk(const int64_t *rowptr /* [V+1] */, const int32_t *post_doc,
+                  const int32_t *post_tf, const float *doclen /* [n_docs] */,
+                  const double *idf /* [V] */, double avgdl, double k1, double b,
+                  int64_t n_docs, int64_t id_base, const int32_t *query_terms, int n_queries,
+                  int max_terms, int k, double *out_scores, int64_t *out_ids,
+                  int32_t *out_counts, thr_stream_t stream);
+
+/* a4  graph channel: bounded BFS (<= hops) from seed entities over the
+ * entity CSR, then score(chunk) = sum_e conf(e,chunk)/(1+dist(e)) over the
+ * entity->chunk mention CSR (ascending entity id, float64).
+ * Stands where GraphSearcher.search is called, retrieval.py:316-356
+ * (src/voice_agent/rag2/graph_search.py:290-418; score form
+ * triple-hybrid-rag/src/triple_hybrid_rag/graph/puppygraph.py:152-167).
+ * men_chunk holds GLOBAL chunk ids; only [chunk_base, chunk_base+n_chunks)
+ * are scored (document sharding).  ``workspace`` >= thr_graph_workspace_bytes. */
+size_t thr_graph_workspace_bytes(int n_queries);
+int thr_graph_topk(const int64_t *ent_rowptr, const int32_t *ent_col, int64_t n_entities,
+                   const int64_t *men_rowptr, const int32_t *men_chunk, const float *men_conf,
+                   int64_t chunk_base, int64_t n_chunks, const int32_t *query_seeds,
+                   int n_queries, int max_seeds, int hops, int k, double *out_scores,
+                   int64_t *out_ids, int32_t *out_counts, uint32_t *out_flags, void *workspace,
+                   size_t workspace_bytes, thr_stream_t stream);
+
+/* a5+a6  candidate merge + weighted Reciprocal Rank Fusion, bit-for-bit the
+ * float64 arithmetic and stable ordering of RAG2Retriever._retrieve_candidates
+ * / _fuse_rrf, src/voice_agent/rag2/retrieval.py:203-271, 358-376.
+ * Channel inputs are ranked id lists [nq, n_*] (negative id = end of list);
+ * a null pointer or n_* == 0 disables the channel. */
+int thr_rrf_fuse(const int64_t *lex_ids, int n_lex, const int64_t *sem_ids, int n_sem,
+                 const int64_t *graph_ids, int n_graph, int n_queries, double w_lex, double w_sem,
+                 double w_graph, int rrf_k, int top_k, int64_t *out_ids /* [nq,top_k] */,
+                 double *out_scores /* [nq,top_k] */, int32_t *out_ranks /* [nq,top_k,3] or NULL */,
+                 int32_t *out_counts, thr_stream_t stream);
+
+/* a8  late-interaction rerank: MaxSim(q, c) = sum_i max_j <q_i, d_cj> with
+ * float16 token matrices on MFMA (float32 accumulate).
+ * Stands where Qwen3VLReranker._rerank_batch_native is called,
+ * retrieval.py:427 (src/voice_agent/retrieval/reranker.py:287-354).
+ * cand [nq, n_cand] are LOCAL doc indices into dtok, negative = padding
+ * (score -inf).  q_tokens, d_tokens multiples of 32; tok_dim multiple of 16. */
+int thr_maxsim(const uint16_t *qtok /* f16 [nq,q_tokens,tok_dim] */, int n_queries, int q_tokens,
+               const uint16_t *dtok /* f16 [n_docs,d_tokens,tok_dim] */, int64_t n_docs,
+               int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
+               float *out_scores /* [nq,n_cand] */, thr_stream_t stream);
+
+/* Merge step of the multi-GPU path: G per-shard ranked lists -> global top-k
+ * under (score desc, id asc).  in_* are [n_queries, n_lists, k_in] as laid out
+ * by an all-gather of each rank's [n_queries, k_in] block. */
+int thr_merge_topk(const double *in_scores, const int64_t *in_ids, int n_queries, int n_lists,
+                   int k_in, int k_out, double *out_scores, int64_t *out_ids, int32_t *out_counts,
+                   thr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THR_HIP_H */

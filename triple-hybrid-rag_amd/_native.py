@@ -1,0 +1,322 @@
+"""ctypes binding of libthr_hip.so (include/thr_hip.h) over PyTorch-ROCm tensors.
+
+PyTorch is used for device memory, streams and torch.distributed only; every
+scorer is a hand-written HIP kernel behind the C ABI.  There is NO CPU or
+eager-PyTorch fallback: if the library is missing or a call fails, this module
+raises.  Operand shapes/dtypes/devices are validated here, on the host, before
+any kernel is launched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _build
+
+THR_FLAG_CERTIFIED = 1
+THR_FLAG_OVERFLOW = 2
+THR_FLAG_EXACT = 4
+THR_DENSE_MAX_K = 256
+THR_BM25_MAX_TERMS = 32
+THR_GRAPH_MAX_SEEDS = 16
+THR_RRF_MAX_PER_CHANNEL = 128
+THR_TOPK_MAX = 128
+ABI_VERSION = 1
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_i64, _i32, _dbl, _sz, _vp = C.c_int64, C.c_int, C.c_double, C.c_size_t, C.c_void_p
+_SIGNATURES = {
+    "thr_abi_version": (C.c_int, []),
+    "thr_error_string": (C.c_char_p, [_i32]),
+    "thr_device_info": (_i32, [C.POINTER(_i32), C.POINTER(_i64), C.c_char_p, _i32]),
+    "thr_embed_postproc": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "thr_doc_norms": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "thr_dense_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "thr_dense_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _vp,
+                              _vp, _vp, _vp, _sz, _vp]),
+    "thr_dense_exact_workspace_bytes": (_sz, [_i64, _i32]),
+    "thr_dense_topk_exact": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
+                                    _vp, _vp, _sz, _vp]),
+    "thr_dense_scan_probe": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
+                             _i32, _i32, _vp, _vp, _vp, _vp]),
+    "thr_graph_workspace_bytes": (_sz, [_i32]),
+    "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32,
+                              _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "thr_rrf_fuse": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
+                            _vp, _vp, _vp, _vp, _vp]),
+    "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load libthr_hip.so; raises NativeError when it cannot (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise NativeError(f"{path} is missing: build it with __graft_entry__.build()")
+        _build.build_native()
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # pragma: no cover
+        raise NativeError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeError(f"{path} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.thr_abi_version() != ABI_VERSION:
+        raise NativeError("libthr_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().thr_error_string(rc).decode()
+        raise NativeError(f"{what} failed: {msg} (code {rc})")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Optional[torch.Tensor], dtype, name: str, ndim: Optional[int] = None) -> int:
+    if t is None:
+        return 0
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise NativeError(f"{name}: expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise NativeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise NativeError(f"{name}: must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise NativeError(f"{name}: expected {ndim} dims, got {t.dim()}")
+    return t.data_ptr()
+
+
+def device_info() -> Tuple[int, int, str]:
+    cus, hbm = C.c_int(0), C.c_int64(0)
+    arch = C.create_string_buffer(128)
+    torch.cuda.current_device()  # make sure the HIP context exists on the right device
+    _check(load().thr_device_info(C.byref(cus), C.byref(hbm), arch, 128), "thr_device_info")
+    return cus.value, hbm.value, arch.value.decode()
+
+
+# --------------------------------------------------------------------- a1
+def embed_postproc(full: torch.Tensor, store_dim: int) -> torch.Tensor:
+    p = _dev(full, torch.float32, "full", 2)
+    n, fd = full.shape
+    out = torch.empty((n, min(fd, store_dim)), dtype=torch.float32, device=full.device)
+    if n:
+        _check(load().thr_embed_postproc(p, n, fd, store_dim, out.data_ptr(), _stream()),
+               "thr_embed_postproc")
+    return out
+
+
+def doc_norms(docs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    p = _dev(docs, torch.float32, "docs", 2)
+    n, d = docs.shape
+    dn = torch.empty(n, dtype=torch.float64, device=docs.device)
+    inv = torch.empty(n, dtype=torch.float32, device=docs.device)
+    if n:
+        _check(load().thr_doc_norms(p, n, d, dn.data_ptr(), inv.data_ptr(), _stream()),
+               "thr_doc_norms")
+    return dn, inv
+
+
+# --------------------------------------------------------------------- a2
+def dense_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int) -> int:
+    return int(load().thr_dense_workspace_bytes(n_docs, dim, n_queries, kprime))
+
+
+def _alloc_out(nq: int, k: int, device):
+    return (torch.empty((nq, k), dtype=torch.float64, device=device),
+            torch.empty((nq, k), dtype=torch.int64, device=device),
+            torch.empty(nq, dtype=torch.int32, device=device),
+            torch.empty(nq, dtype=torch.int32, device=device))
+
+
+def dense_topk(docs, dnorm, inv_norm, queries, k: int, kprime: int, id_base: int = 0,
+               workspace: Optional[torch.Tensor] = None):
+    """-> (scores f64 [nq,k], ids i64 [nq,k], counts i32 [nq], flags i32 [nq])."""
+    pd = _dev(docs, torch.float32, "docs", 2)
+    n, d = docs.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    nq = queries.shape[0]
+    if queries.shape[1] != d:
+        raise NativeError(f"queries dim {queries.shape[1]} != docs dim {d}")
+    pn = _dev(dnorm, torch.float64, "dnorm", 1)
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    if dnorm.shape[0] != n or inv_norm.shape[0] != n:
+        raise NativeError("dnorm / inv_norm length != n_docs")
+    need = dense_workspace_bytes(n, d, nq, kprime)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    S, I, cnt, flg = _alloc_out(nq, k, docs.device)
+    _check(load().thr_dense_topk(pd, pn, pi, n, d, id_base, pq, nq, k, kprime, S.data_ptr(),
+                                 I.data_ptr(), cnt.data_ptr(), flg.data_ptr(), pw,
+                                 workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_topk")
+    return S, I, cnt, flg
+
+
+def dense_topk_exact(docs, dnorm, queries, k: int, id_base: int = 0):
+    pd = _dev(docs, torch.float32, "docs", 2)
+    n, d = docs.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    nq = queries.shape[0]
+    if queries.shape[1] != d:
+        raise NativeError(f"queries dim {queries.shape[1]} != docs dim {d}")
+    pn = _dev(dnorm, torch.float64, "dnorm", 1)
+    if dnorm.shape[0] != n:
+        raise NativeError("dnorm length != n_docs")
+    need = int(load().thr_dense_exact_workspace_bytes(n, nq))
+    ws = torch.empty(need, dtype=torch.uint8, device=docs.device)
+    S, I, cnt, flg = _alloc_out(nq, k, docs.device)
+    _check(load().thr_dense_topk_exact(pd, pn, n, d, id_base, pq, nq, k, S.data_ptr(),
+                                       I.data_ptr(), cnt.data_ptr(), flg.data_ptr(),
+                                       ws.data_ptr(), need, _stream()), "thr_dense_topk_exact")
+    return S, I, cnt, flg
+
+
+def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
+    pd = _dev(docs, torch.float32, "docs", 2)
+    n, d = docs.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    if queries.shape[1] != d or inv_norm.shape[0] != n:
+        raise NativeError("probe: shape mismatch")
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    _check(load().thr_dense_scan_probe(pd, pi, n, d, pq, queries.shape[0], pw,
+                                       workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_scan_probe")
+
+
+# --------------------------------------------------------------------- a3
+def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms, k: int,
+              id_base: int = 0, k1: float = 1.2, b: float = 0.75):
+    pr = _dev(rowptr, torch.int64, "rowptr", 1)
+    pdoc = _dev(post_doc, torch.int32, "post_doc", 1)
+    ptf = _dev(post_tf, torch.int32, "post_tf", 1)
+    pdl = _dev(doclen, torch.float32, "doclen", 1)
+    pidf = _dev(idf, torch.float64, "idf", 1)
+    pqt = _dev(query_terms, torch.int32, "query_terms", 2)
+    if post_doc.shape != post_tf.shape or idf.shape[0] + 1 != rowptr.shape[0]:
+        raise NativeError("bm25: CSR arrays are inconsistent")
+    nq, mt = query_terms.shape
+    if mt > THR_BM25_MAX_TERMS or k > THR_TOPK_MAX:
+        raise NativeError("bm25: too many terms per query or k too large")
+    S, I, cnt, _ = _alloc_out(nq, k, rowptr.device)
+    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, avgdl, k1, b, doclen.shape[0], id_base,
+                                pqt, nq, mt, k, S.data_ptr(), I.data_ptr(), cnt.data_ptr(),
+                                _stream()), "thr_bm25_topk")
+    return S, I, cnt
+
+
+# --------------------------------------------------------------------- a4
+def graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, query_seeds, hops: int,
+               k: int, chunk_base: int, n_chunks: int):
+    per = _dev(ent_rowptr, torch.int64, "ent_rowptr", 1)
+    pec = _dev(ent_col, torch.int32, "ent_col", 1)
+    pmr = _dev(men_rowptr, torch.int64, "men_rowptr", 1)
+    pmc = _dev(men_chunk, torch.int32, "men_chunk", 1)
+    pmw = _dev(men_conf, torch.float32, "men_conf", 1)
+    pqs = _dev(query_seeds, torch.int32, "query_seeds", 2)
+    if ent_rowptr.shape != men_rowptr.shape or men_chunk.shape != men_conf.shape:
+        raise NativeError("graph: CSR arrays are inconsistent")
+    nq, ms = query_seeds.shape
+    if ms > THR_GRAPH_MAX_SEEDS or k > THR_TOPK_MAX:
+        raise NativeError("graph: too many seeds per query or k too large")
+    need = int(load().thr_graph_workspace_bytes(nq))
+    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=ent_rowptr.device)
+    S, I, cnt, flg = _alloc_out(nq, k, ent_rowptr.device)
+    _check(load().thr_graph_topk(per, pec, ent_rowptr.shape[0] - 1, pmr, pmc, pmw, chunk_base,
+                                 n_chunks, pqs, nq, ms, hops, k, S.data_ptr(), I.data_ptr(),
+                                 cnt.data_ptr(), flg.data_ptr(), ws.data_ptr(), need, _stream()),
+           "thr_graph_topk")
+    return S, I, cnt, flg
+
+
+# ----------------------------------------------------------------- a5 + a6
+def rrf_fuse(lex_ids, sem_ids, graph_ids, top_k: int, w_lex: float = 0.7, w_sem: float = 0.8,
+             w_graph: float = 1.0, rrf_k: int = 60, want_ranks: bool = False):
+    chans = [lex_ids, sem_ids, graph_ids]
+    ref = next(c for c in chans if c is not None)
+    nq = ref.shape[0]
+    ptrs, widths = [], []
+    for name, c in zip(("lex_ids", "sem_ids", "graph_ids"), chans):
+        if c is None:
+            ptrs.append(0)
+            widths.append(0)
+            continue
+        ptrs.append(_dev(c, torch.int64, name, 2))
+        if c.shape[0] != nq or c.shape[1] > THR_RRF_MAX_PER_CHANNEL:
+            raise NativeError(f"rrf: bad shape for {name}")
+        widths.append(c.shape[1])
+    dev = ref.device
+    out_ids = torch.empty((nq, top_k), dtype=torch.int64, device=dev)
+    out_sc = torch.empty((nq, top_k), dtype=torch.float64, device=dev)
+    out_rk = torch.empty((nq, top_k, 3), dtype=torch.int32, device=dev) if want_ranks else None
+    cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+    _check(load().thr_rrf_fuse(ptrs[0], widths[0], ptrs[1], widths[1], ptrs[2], widths[2], nq,
+                               w_lex, w_sem, w_graph, rrf_k, top_k, out_ids.data_ptr(),
+                               out_sc.data_ptr(), out_rk.data_ptr() if want_ranks else 0,
+                               cnt.data_ptr(), _stream()), "thr_rrf_fuse")
+    return out_ids, out_sc, out_rk, cnt
+
+
+# --------------------------------------------------------------------- a8
+def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+    pq = _dev(qtok, torch.float16, "qtok", 3)
+    pdt = _dev(dtok, torch.float16, "dtok", 3)
+    pc = _dev(cand, torch.int32, "cand", 2)
+    nq, qt, td = qtok.shape
+    nd, dt, td2 = dtok.shape
+    if td != td2 or cand.shape[0] != nq:
+        raise NativeError("maxsim: shape mismatch")
+    if qt % 32 or dt % 32 or td % 16:
+        raise NativeError("maxsim: q_tokens/d_tokens must be multiples of 32, tok_dim of 16")
+    if cand.numel() and int(cand.max()) >= nd:
+        raise NativeError("maxsim: candidate index out of range")
+    out = torch.empty(cand.shape, dtype=torch.float32, device=qtok.device)
+    _check(load().thr_maxsim(pq, nq, qt, pdt, nd, dt, td, pc, cand.shape[1], out.data_ptr(),
+                             _stream()), "thr_maxsim")
+    return out
+
+
+# ------------------------------------------------------------- multi-GPU
+def merge_topk(in_scores: torch.Tensor, in_ids: torch.Tensor, k_out: int):
+    """in_* are [n_lists, n_queries, k_in] (the layout an all-gather of each
+    rank's [n_queries, k_in] block produces)."""
+    ps = _dev(in_scores, torch.float64, "in_scores", 3)
+    pi = _dev(in_ids, torch.int64, "in_ids", 3)
+    if in_scores.shape != in_ids.shape:
+        raise NativeError("merge: shape mismatch")
+    nl, nq, kin = in_scores.shape
+    S = torch.empty((nq, k_out), dtype=torch.float64, device=in_scores.device)
+    I = torch.empty((nq, k_out), dtype=torch.int64, device=in_scores.device)
+    cnt = torch.empty(nq, dtype=torch.int32, device=in_scores.device)
+    _check(load().thr_merge_topk(ps, pi, nq, nl, kin, k_out, S.data_ptr(), I.data_ptr(),
+                                 cnt.data_ptr(), _stream()), "thr_merge_topk")
+    return S, I, cnt

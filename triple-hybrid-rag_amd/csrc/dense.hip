@@ -1,0 +1,778 @@
+// Dense channel: exact brute-force cosine top-k on gfx950 (MI355X).
+//
+// Stands where the reference calls SQL rag2_semantic_search
+// (database/migrations/20260114_rag2_schema.sql:377-410, from
+// src/voice_agent/rag2/retrieval.py:304-312): `1 - (embedding <=> q)`
+// ORDER BY distance LIMIT k.  The reference answers it from an approximate
+// HNSW index inside PostgreSQL; this is the exact scan that index approximates.
+//
+// Pipeline per batch of queries (all kernels on one stream, no host sync):
+//   K1 dense_scan<MODE_ALL>     score a strided SAMPLE of doc groups for every query tile
+//   K2 kth_select               tau[q] = k'-th largest sample score (a lower bound on the
+//                               k'-th largest score over the whole corpus)
+//   K3 dense_scan<MODE_FILTER>  THE HBM-bound kernel: stream the corpus once per tile of QT
+//                               queries (queries LDS-resident), fp32 FMA, wave-transpose
+//                               reduction, append (score, doc) >= tau[q] to a candidate list
+//   K4 select_rescore           per query: shortlist k' by fp32 score, re-score in float64
+//                               with sequential accumulation (the oracle's contract), sort
+//                               (score desc, doc asc), certify with the fp32 error bound
+// Algorithmic HBM bytes of K3 = n_docs * dim * 4 per tile pass.
+#include "thr_common.hpp"
+
+namespace thr {
+
+constexpr int SCAN_THREADS = 512;          // 8 waves share one LDS query tile
+constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
+constexpr int CHUNK = 256;                 // floats per wave-wide float4 load (1 KiB)
+constexpr int MODE_ALL = 0, MODE_FILTER = 1;
+constexpr int CAND_CAP = 16384;            // candidates kept per query between K3 and K4
+constexpr int SAMPLE_TARGET = 32768;       // sample docs for the tau estimate
+constexpr int WBUF = 256;                  // per-wave LDS staging slots for passing rows
+constexpr int ROW_BITS = 27;               // tile-list entries pack (query-in-tile << 27 | row)
+constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
+
+struct Cand {
+    float score;
+    uint32_t doc;
+};
+
+// ---------------------------------------------------------------------------
+// wave-transpose reduction: every lane holds V partial sums v[0..V); afterwards
+// lane l holds the 64-lane totals of elements (V/64)*l + j, j < V/64, in v[j].
+// ---------------------------------------------------------------------------
+// one butterfly level over lane bit M with N live values per lane (static indexing only:
+// a runtime-indexed register array would be demoted to scratch)
+template <int N, int M, int V>
+__device__ __forceinline__ void reduce_levels_shfl(float (&v)[V], int lane) {
+    const bool hi = (lane & M) != 0;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        float keep = hi ? v[j + N / 2] : v[j];
+        float give = hi ? v[j] : v[j + N / 2];
+        v[j] = keep + __shfl_xor(give, M, WAVE);
+    }
+    if constexpr (M > 1) reduce_levels_shfl<N / 2, M / 2, V>(v, lane);
+}
+
+template <int V, bool SWAPS>
+__device__ __forceinline__ void wave_transpose_reduce(float (&v)[V], int lane) {
+    static_assert(V >= 64 && (V & (V - 1)) == 0, "V must be a power of two >= 64");
+    if constexpr (SWAPS) {
+        // lanes l / l+32: v_permlane32_swap exchanges the upper half of its first operand
+        // with the lower half of its second, so a+b afterwards is the pair sum of v[j] in
+        // the lower lane and of v[j+V/2] in the upper lane; v_permlane16_swap does the same
+        // between the odd and even 16-lane rows.
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) {
+            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]),
+                                                      __float_as_uint(v[j + V / 2]), false, false);
+            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < V / 4; ++j) {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]),
+                                                      __float_as_uint(v[j + V / 4]), false, false);
+            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        reduce_levels_shfl<V / 4, 8, V>(v, lane);
+    } else {
+        reduce_levels_shfl<V, 32, V>(v, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 / K3: the streaming scan.
+//   QT   queries per tile (LDS-resident, [QT][dim] floats)
+//   R    doc rows per wave per step (register blocking: each LDS query read feeds R rows)
+//   NCH  dim / 256
+// A wave owns R consecutive rows; lane l holds dims [256c + 4l, +4) of each row for
+// chunk c (one fully coalesced 1 KiB load per row and chunk), accumulates R*QT partial
+// dots, then the wave-transpose reduction leaves (R*QT)/64 finished dots per lane.
+// ---------------------------------------------------------------------------
+template <int QT, int R, int NCH, int MODE, bool SWAPS>
+__global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
+    const float* __restrict__ docs, const float* __restrict__ inv_norm, int64_t n_docs,
+    const float* __restrict__ queries, int n_queries,
+    int64_t n_groups,      // doc groups (of R rows) this launch visits
+    int64_t group_stride,  // actual group = visited index * group_stride
+    const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
+    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
+    constexpr int D = NCH * CHUNK;
+    constexpr int V = R * QT;
+    constexpr int NF = V / 64;  // finished values per lane
+    extern __shared__ float4 lds_q[];  // [QT][D/4], then SCAN_WAVES * WBUF staging slots
+
+    const int tile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane lets hipcc keep everything derived from it
+    // (group index, row bases, loop control) in SGPRs and scalar ALU
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    Cand* wbuf = reinterpret_cast<Cand*>(lds_q + QT * (D / 4)) + wave * WBUF;
+    int wcnt = 0;  // wave-uniform fill of wbuf
+    // Rows that pass the filter are staged in LDS and copied out in bulk: a returning global
+    // atomic per passing row would sit in the in-order vmcnt queue behind 12 KiB of prefetch
+    // and drain it, and any VMEM store left pending at the loop back-edge makes hipcc fall
+    // back to vmcnt(0) waits everywhere in the loop.
+    auto flush = [&]() {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&tile_cnt[tile], wcnt);
+        base = __shfl(base, 0, WAVE);
+        for (int i = lane; i < wcnt; i += WAVE)
+            if (base + i < tile_cap) tile_list[(int64_t)tile * tile_cap + base + i] = wbuf[i];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing but loads pending afterwards
+        wcnt = 0;
+    };
+
+    // stage the query tile (rows past n_queries are zero)
+    for (int i = threadIdx.x; i < QT * (D / 4); i += SCAN_THREADS) {
+        const int q = tile * QT + i / (D / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < n_queries)
+            v = reinterpret_cast<const float4*>(queries)[(int64_t)q * (D / 4) + i % (D / 4)];
+        lds_q[i] = v;
+    }
+    __syncthreads();
+
+    // what this lane owns after the reduction: element e = NF*lane + j -> (row e/QT, query e%QT)
+    float my_tau[NF];
+    int my_q[NF], my_r[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        int e = NF * lane + j;
+        my_q[j] = e % QT;
+        my_r[j] = e / QT;
+        my_tau[j] = MODE == MODE_FILTER ? tau[tile * QT + my_q[j]] : 0.f;
+    }
+
+    const int64_t wave_id = (int64_t)blockIdx.x * SCAN_WAVES + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * SCAN_WAVES;
+    const float4* docs4 = reinterpret_cast<const float4*>(docs);
+
+    // The order of LDS reads, global loads and FMAs below is pinned with empty volatile
+    // asm statements: THR_PIN(x) makes x opaque at that point, so a load whose address is
+    // pinned cannot be hoisted above it and arithmetic feeding a pinned value cannot sink
+    // below it.  Left alone, hipcc clusters all ds_reads of a chunk ahead of the FMAs and
+    // spills the accumulators.
+#define THR_PIN(x) asm volatile("" : "+v"(x))
+    // d[c] holds chunk c of the R rows being computed; as soon as chunk c has been consumed
+    // the same registers are refilled with chunk c of the wave's NEXT group, so NCH-1 chunk
+    // stages (8 KiB per wave at dim 768) are always in flight and no register copies exist.
+    float4 d[NCH][R];
+    // Row bases are wave-uniform float4 offsets held in SGPRs (pinned as scalars: a pinned
+    // POINTER would lose its address space and load as flat_*); the lane adds its 16 bytes.
+#define THR_PIN_S(x) asm volatile("" : "+s"(x))
+    int64_t ptr[R];
+    auto set_ptrs = [&](int64_t g) {
+        int64_t row0 = g * group_stride * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int64_t row = row0 + r;
+            row = row < n_docs ? row : n_docs - 1;  // clamp: tail rows are masked at emission
+            ptr[r] = row * (D / 4);
+        }
+    };
+
+    int64_t g = wave_id;
+    if (g < n_groups) {
+        set_ptrs(g);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                THR_PIN_S(ptr[r]);  // same issue order as the steady state: exact vmcnt counts
+                d[c][r] = docs4[ptr[r] + c * (CHUNK / 4) + lane];
+            }
+    }
+    for (; g < n_groups; g += wave_stride) {
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.f;
+        // 1/||d|| of the rows this lane will emit, requested BEFORE the chunk loop so that it
+        // is the oldest outstanding load at emission time (vmcnt retires in order; a load
+        // issued after the prefetches would drain all of them)
+        const int64_t row0 = g * group_stride * R;
+        float inv[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            int idx = my_r[j];
+            if (row0 + idx >= n_docs) idx = (int)(n_docs - 1 - row0);
+            THR_PIN(idx);
+            inv[j] = inv_norm[row0 + idx];
+        }
+        // The refill is unconditional (the wave's last group re-requests itself): a prefetch
+        // under a branch leaves two possible queue depths at every later wait and hipcc then
+        // waits for the shallower one, i.e. over-waits by a whole chunk stage.
+        set_ptrs(g + wave_stride < n_groups ? g + wave_stride : g);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            // query values run two LDS reads ahead of their FMAs
+            int qi = c * (CHUNK / 4) + lane;
+            THR_PIN(qi);
+            float4 q0 = lds_q[qi], q1 = lds_q[qi + (D / 4)];
+#pragma unroll
+            for (int q = 0; q < QT; ++q) {
+                const float4 qv = q0;
+                q0 = q1;
+                if (q + 2 < QT) {
+                    THR_PIN(qi);
+                    q1 = lds_q[qi + (q + 2) * (D / 4)];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    float a = acc[r * QT + q];
+                    a = __builtin_fmaf(d[c][r].x, qv.x, a);
+                    a = __builtin_fmaf(d[c][r].y, qv.y, a);
+                    a = __builtin_fmaf(d[c][r].z, qv.z, a);
+                    a = __builtin_fmaf(d[c][r].w, qv.w, a);
+                    acc[r * QT + q] = a;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) THR_PIN(acc[r * QT + q]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                THR_PIN_S(ptr[r]);
+                d[c][r] = docs4[ptr[r] + c * (CHUNK / 4) + lane];
+            }
+        }
+#undef THR_PIN
+#undef THR_PIN_S
+        wave_transpose_reduce<V, SWAPS>(acc, lane);
+
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int64_t row = row0 + my_r[j];
+            const bool ok = row < n_docs;
+            const float sc = acc[j] * inv[j];
+            if constexpr (MODE == MODE_ALL) {
+                int q = tile * QT + my_q[j];
+                sample_scores[(int64_t)q * sample_ld + g * R + my_r[j]] =
+                    (ok && inv[j] > 0.f) ? sc : -INFINITY;
+            } else {
+                const bool pass = ok && inv[j] > 0.f && sc >= my_tau[j];
+                const uint64_t m = __ballot(pass);
+                if (m) {
+                    const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pass) wbuf[pos] = Cand{sc, ((uint32_t)my_q[j] << ROW_BITS) | (uint32_t)row};
+                    wcnt += __popcll(m);
+                }
+            }
+        }
+        if constexpr (MODE == MODE_FILTER) {
+            if (wcnt > WBUF - NF * WAVE) flush();
+        }
+    }
+    if constexpr (MODE == MODE_FILTER) {
+        if (wcnt > 0) flush();
+    }
+}
+
+// K3b: split a tile's mixed candidate list into the per-query lists K4 reads.
+__global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__ tile_cnt,
+                                                         const Cand* __restrict__ tile_list,
+                                                         int tile_cap, int qtile,
+                                                         int* __restrict__ cand_cnt,
+                                                         Cand* __restrict__ cand) {
+    const int tile = blockIdx.y;
+    int n = tile_cnt[tile];
+    n = n < tile_cap ? n : tile_cap;
+    const Cand* list = tile_list + (int64_t)tile * tile_cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Cand e = list[i];
+        const int q = tile * qtile + (int)(e.doc >> ROW_BITS);
+        const int p = atomicAdd(&cand_cnt[q], 1);
+        if (p < CAND_CAP) cand[(int64_t)q * CAND_CAP + p] = Cand{e.score, e.doc & ROW_MASK};
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 8-bit-digit radix select of the kk-th largest key among n (block-wide).
+// keyfn(i) -> uint32 order-preserving key.  Returns the key; *n_greater gets the
+// number of keys strictly greater.  hist = 256 ints of LDS, bc = 4 ints of LDS.
+// ---------------------------------------------------------------------------
+template <typename KeyFn>
+__device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, int* bc, int* n_greater) {
+    uint32_t prefix = 0, mask = 0;
+    int remaining = kk, greater = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            uint32_t key = keyfn(i);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cum = 0, b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= remaining) break;
+                cum += hist[b];
+            }
+            bc[0] = b;
+            bc[1] = cum;
+        }
+        __syncthreads();
+        int b = bc[0];
+        remaining -= bc[1];
+        greater += bc[1];
+        prefix |= (uint32_t)b << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    *n_greater = greater;
+    return prefix;
+}
+
+// K2: tau[q] = kk-th largest of sample_scores[q][0..n_sample)
+__global__ __launch_bounds__(256) void kth_select(const float* __restrict__ sample_scores,
+                                                  int64_t sample_ld, int n_sample, int kk,
+                                                  float* __restrict__ tau) {
+    __shared__ int hist[256];
+    __shared__ int bc[4];
+    const float* s = sample_scores + (int64_t)blockIdx.x * sample_ld;
+    int greater;
+    uint32_t key = block_radix_select([&](int i) { return fkey(s[i]); }, n_sample,
+                                      kk < n_sample ? kk : n_sample, hist, bc, &greater);
+    if (threadIdx.x == 0) tau[blockIdx.x] = n_sample >= kk ? fkey_inv(key) : -INFINITY;
+}
+
+__global__ void fill_f32(float* p, int n, float v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// sequential float64 accumulation of float32 products: the oracle's contract
+// (oracle/thr_oracle.py seq_dot_f64).  Products are exact in float64.
+__device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const float* b, int d) {
+    double s = 0.0;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    for (int i = 0; i < d / 4; ++i) {
+        float4 x = a4[i];
+        s = __dadd_rn(s, __dmul_rn((double)x.x, (double)b[4 * i + 0]));
+        s = __dadd_rn(s, __dmul_rn((double)x.y, (double)b[4 * i + 1]));
+        s = __dadd_rn(s, __dmul_rn((double)x.z, (double)b[4 * i + 2]));
+        s = __dadd_rn(s, __dmul_rn((double)x.w, (double)b[4 * i + 3]));
+    }
+    return s;
+}
+
+// K4: shortlist, float64 rescoring, ordering, certificate.  One block per query.
+constexpr int SEL_THREADS = 256;
+__global__ __launch_bounds__(SEL_THREADS) void select_rescore(
+    const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
+    const float* __restrict__ queries, const float* __restrict__ tau,
+    const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
+    const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps,
+    double* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+    int32_t* __restrict__ out_counts, uint32_t* __restrict__ out_flags) {
+    extern __shared__ float lds_qv[];  // [dim] query
+    __shared__ int hist[256];
+    __shared__ int bc[4];
+    __shared__ double s_s[THR_DENSE_MAX_K];
+    __shared__ int64_t s_id[THR_DENSE_MAX_K];
+    __shared__ int n_sel;
+    __shared__ double s_qn;
+
+    const int q = blockIdx.x;
+    const Cand* c = cand + (int64_t)q * CAND_CAP;
+    const int cnt = cand_cnt[q];
+    const bool overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
+    const int n = overflow ? CAND_CAP : cnt;
+
+    for (int i = threadIdx.x; i < dim; i += SEL_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
+    for (int i = threadIdx.x; i < THR_DENSE_MAX_K; i += SEL_THREADS) {
+        s_s[i] = -INFINITY;
+        s_id[i] = INT64_MAX;
+    }
+    if (threadIdx.x == 0) n_sel = 0;
+    __syncthreads();
+
+    // shortlist: the kprime best float32 scores (ties at the floor: first come)
+    float floor32 = tau[q];
+    if (n > kprime) {
+        int greater;
+        uint32_t tkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, kprime, hist,
+                                           bc, &greater);
+        floor32 = fkey_inv(tkey);
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+            if (fkey(c[i].score) > tkey) {
+                int p = atomicAdd(&n_sel, 1);
+                s_id[p] = c[i].doc;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+            if (fkey(c[i].score) == tkey) {
+                int p = atomicAdd(&n_sel, 1);
+                if (p < kprime) s_id[p] = c[i].doc;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0 && n_sel > kprime) n_sel = kprime;
+    } else {
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS) s_id[i] = c[i].doc;
+        if (threadIdx.x == 0) n_sel = n;
+    }
+    __syncthreads();
+    const int ns = n_sel;
+
+    // float64 rescoring, one thread per shortlisted row; the last thread takes ||q||
+    if (threadIdx.x == SEL_THREADS - 1) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
+    double dot = 0.0;
+    int64_t row = -1;
+    if (threadIdx.x < ns) {
+        row = s_id[threadIdx.x];
+        dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
+    }
+    __syncthreads();
+    if (threadIdx.x < ns) {
+        const double qn = s_qn, dn = dnorm[row];
+        double sim = -INFINITY;
+        if (dn > 0.0) sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
+        s_s[threadIdx.x] = sim;
+        s_id[threadIdx.x] = sim == -INFINITY ? INT64_MAX : row + id_base;
+    }
+    __syncthreads();
+    bitonic_sort_desc<THR_DENSE_MAX_K>(s_s, s_id);
+
+    // results + certificate
+    int valid = 0;
+    for (int i = 0; i < k; ++i) valid += (s_s[i] > -INFINITY) ? 1 : 0;  // k <= 256, uniform
+    for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+        bool ok = s_s[i] > -INFINITY;
+        out_scores[(int64_t)q * k + i] = ok ? s_s[i] : -INFINITY;
+        out_ids[(int64_t)q * k + i] = ok ? s_id[i] : -1;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t flag = overflow ? THR_FLAG_OVERFLOW : 0u;
+        bool cert;
+        if (overflow) {
+            cert = false;
+        } else if (floor32 == -INFINITY) {
+            cert = true;  // every row with an embedding was rescored
+        } else if (valid < k) {
+            cert = false;
+        } else {
+            // rows outside the shortlist have fp32 score <= floor32, hence true
+            // cosine <= floor32/||q|| + eps; the k-th best must clear that strictly.
+            cert = s_qn > 0.0 && (s_s[k - 1] - (double)floor32 / s_qn) > eps;
+        }
+        out_flags[q] = flag | (cert ? THR_FLAG_CERTIFIED : 0u);
+        out_counts[q] = valid;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exhaustive float64 path: every row scored with the oracle's arithmetic, then an
+// exact block top-k per (query, slab); slabs merged by a second kernel.
+// ---------------------------------------------------------------------------
+constexpr int EX_THREADS = 256;
+constexpr int EX_CAP = 1024;
+constexpr int EX_SLABS = 64;
+
+__global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
+    const float* __restrict__ docs, const double* __restrict__ dnorm, int64_t n_docs, int dim,
+    const float* __restrict__ queries, int k, double* __restrict__ slab_s,
+    int64_t* __restrict__ slab_id) {
+    extern __shared__ float lds_qv[];
+    __shared__ double b_s[EX_CAP];
+    __shared__ int64_t b_id[EX_CAP];
+    __shared__ int b_cnt;
+    __shared__ double t_s;
+    __shared__ int64_t t_id;
+    __shared__ double s_qn;
+    const int q = blockIdx.y, slab = blockIdx.x;
+    for (int i = threadIdx.x; i < dim; i += EX_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
+    __syncthreads();
+    if (threadIdx.x == 0) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
+    BlockTopK<EX_CAP> tk;
+    tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k);
+    const double qn = s_qn;
+    const int64_t per = (n_docs + EX_SLABS - 1) / EX_SLABS;
+    const int64_t lo = slab * per, hi = (lo + per < n_docs) ? lo + per : n_docs;
+    for (int64_t base = lo; base < hi; base += EX_THREADS) {
+        int64_t row = base + threadIdx.x;
+        bool ok = row < hi;
+        double sim = -INFINITY;
+        if (ok) {
+            double dn = dnorm[row];
+            if (dn > 0.0) {
+                double dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
+                sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
+            }
+        }
+        tk.push(ok && sim > -INFINITY, sim, row);
+    }
+    int n = tk.finish();
+    for (int i = threadIdx.x; i < k; i += EX_THREADS) {
+        int64_t o = ((int64_t)q * EX_SLABS + slab) * k + i;
+        slab_s[o] = i < n ? b_s[i] : -INFINITY;
+        slab_id[o] = i < n ? b_id[i] : INT64_MAX;
+    }
+}
+
+// merges n_lists ranked lists of k_in per query (layout [n_lists? no: q-major]) -> top k_out
+__global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in_s,
+                                                   const int64_t* __restrict__ in_id,
+                                                   int64_t q_stride, int64_t list_stride,
+                                                   int n_lists, int k_in, int k_out,
+                                                   int64_t id_add, uint32_t flag_value,
+                                                   double* __restrict__ out_s,
+                                                   int64_t* __restrict__ out_id,
+                                                   int32_t* __restrict__ out_counts,
+                                                   uint32_t* __restrict__ out_flags) {
+    __shared__ double b_s[EX_CAP];
+    __shared__ int64_t b_id[EX_CAP];
+    __shared__ int b_cnt;
+    __shared__ double t_s;
+    __shared__ int64_t t_id;
+    const int q = blockIdx.x;
+    BlockTopK<EX_CAP> tk;
+    tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k_out);
+    const int total = n_lists * k_in;
+    for (int base = 0; base < total; base += blockDim.x) {
+        int i = base + threadIdx.x;
+        bool ok = i < total;
+        double s = -INFINITY;
+        int64_t id = INT64_MAX;
+        if (ok) {
+            int64_t o = (int64_t)q * q_stride + (int64_t)(i / k_in) * list_stride + (i % k_in);
+            s = in_s[o];
+            id = in_id[o];
+        }
+        tk.push(ok && s > -INFINITY && id >= 0 && id != INT64_MAX, s, id);
+    }
+    int n = tk.finish();
+    for (int i = threadIdx.x; i < k_out; i += blockDim.x) {
+        out_s[(int64_t)q * k_out + i] = i < n ? b_s[i] : -INFINITY;
+        out_id[(int64_t)q * k_out + i] = i < n ? b_id[i] + id_add : -1;
+    }
+    if (threadIdx.x == 0) {
+        if (out_counts) out_counts[q] = n;
+        if (out_flags) out_flags[q] = flag_value;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct DensePlan {
+    int qtile, ntiles, qpad;
+    int64_t sample_groups, sample_stride, sample_docs;
+    bool sampled;
+    int tile_cap;
+    size_t off_tau, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, total;
+};
+
+constexpr int QT_DEFAULT = 32;
+constexpr int R_DEFAULT = 4;
+
+static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime) {
+    DensePlan p;
+    p.qtile = QT_DEFAULT;
+    p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
+    p.qpad = p.ntiles * p.qtile;
+    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
+    // sample only when the corpus is larger than what the candidate list can hold anyway
+    p.sampled = n_docs > CAND_CAP / 2;
+    int64_t target = n_docs / 32;
+    if (target > SAMPLE_TARGET) target = SAMPLE_TARGET;
+    if (target < 4 * (int64_t)kprime) target = 4 * (int64_t)kprime;
+    int64_t sg = (target + R_DEFAULT - 1) / R_DEFAULT;
+    if (sg > groups) sg = groups;
+    p.sample_stride = sg > 0 ? groups / sg : 1;
+    if (p.sample_stride < 1) p.sample_stride = 1;
+    p.sample_groups = p.sampled ? sg : 0;
+    p.sample_docs = p.sample_groups * R_DEFAULT;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    p.off_tau = take(sizeof(float) * p.qpad);
+    p.tile_cap = p.qtile * (CAND_CAP / 2);
+    p.off_cnt = take(sizeof(int) * p.qpad);   // off_cnt and off_tcnt are zeroed by one memset
+    p.off_tcnt = take(sizeof(int) * p.ntiles);
+    p.off_cand = take(sizeof(Cand) * (size_t)p.qpad * CAND_CAP);
+    p.off_tlist = take(sizeof(Cand) * (size_t)p.ntiles * p.tile_cap);
+    p.off_sample = take(sizeof(float) * (size_t)p.qpad * (size_t)p.sample_docs);
+    p.total = off;
+    return p;
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <int MODE>
+static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
+                       const float* queries, int n_queries, int ntiles, int64_t n_groups,
+                       int64_t group_stride, const float* tau, int* tile_cnt, Cand* tile_list,
+                       int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
+    constexpr int QT = QT_DEFAULT, R = R_DEFAULT;
+    const size_t lds = sizeof(float) * QT * (size_t)dim + sizeof(Cand) * SCAN_WAVES * WBUF;
+    int64_t waves = n_groups;
+    int64_t blocks = (waves + SCAN_WAVES - 1) / SCAN_WAVES;
+    if (blocks > num_cus()) blocks = num_cus();  // one 512-thread block per CU (LDS-bound)
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, (unsigned)ntiles);
+#define THR_SCAN_CASE(NCH)                                                                        \
+    case NCH: {                                                                                   \
+        auto kern = dense_scan<QT, R, NCH, MODE, true>;                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, docs, inv_norm, n_docs,       \
+                           queries, n_queries, n_groups, group_stride, tau, tile_cnt, tile_list,  \
+                           tile_cap, sample, sample_ld);                                          \
+        break;                                                                                    \
+    }
+    switch (dim / CHUNK) {
+        THR_SCAN_CASE(1)
+        THR_SCAN_CASE(2)
+        THR_SCAN_CASE(3)
+        THR_SCAN_CASE(4)
+        default:
+            return THR_ERR_UNSUPPORTED;
+    }
+#undef THR_SCAN_CASE
+    return launch_status();
+}
+
+}  // namespace thr
+
+using namespace thr;
+
+extern "C" size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queries, int kprime) {
+    (void)dim;
+    if (n_docs <= 0 || n_queries <= 0) return 0;
+    return make_plan(n_docs, n_queries, kprime).total;
+}
+
+extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const float* inv_norm,
+                              int64_t n_docs, int dim, int64_t id_base, const float* queries,
+                              int n_queries, int k, int kprime, double* out_scores,
+                              int64_t* out_ids, int32_t* out_counts, uint32_t* out_flags,
+                              void* workspace, size_t workspace_bytes, thr_stream_t stream) {
+    THR_RETURN_IF(!docs || !dnorm || !inv_norm || !queries || !out_scores || !out_ids ||
+                      !out_counts || !out_flags || !workspace,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || kprime < k ||
+                      kprime > THR_DENSE_MAX_K,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(dim <= 0 || dim % CHUNK != 0 || dim / CHUNK > 4, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS, THR_ERR_UNSUPPORTED);
+    const DensePlan p = make_plan(n_docs, n_queries, kprime);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* tau = (float*)(ws + p.off_tau);
+    int* cnt = (int*)(ws + p.off_cnt);
+    int* tcnt = (int*)(ws + p.off_tcnt);
+    Cand* cand = (Cand*)(ws + p.off_cand);
+    Cand* tlist = (Cand*)(ws + p.off_tlist);
+    float* sample = (float*)(ws + p.off_sample);
+
+    hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
+    if (e != hipSuccess) return (int)e;
+    int rc;
+    if (p.sampled) {
+        rc = launch_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+                                   p.sample_groups, p.sample_stride, nullptr, nullptr, nullptr, 0,
+                                   sample, p.sample_docs, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
+                           (int)p.sample_docs, kprime, tau);
+    } else {
+        hipLaunchKernelGGL(fill_f32, dim3((p.qpad + 255) / 256), dim3(256), 0, st, tau, p.qpad,
+                           -INFINITY);
+    }
+    if ((rc = launch_status())) return rc;
+    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
+    rc = launch_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles, groups,
+                                  1, tau, tcnt, tlist, p.tile_cap, nullptr, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bucket_candidates, dim3(64, p.ntiles), dim3(256), 0, st, tcnt, tlist,
+                       p.tile_cap, p.qtile, cnt, cand);
+    if ((rc = launch_status())) return rc;
+    // fp32 error bound of the scan: dim/64 chained FMAs per lane + 6 tree adds + 2 roundings
+    const double eps = ((double)dim / 16.0 + 16.0) * 5.9604644775390625e-08;
+    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), sizeof(float) * dim, st,
+                       docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
+                       p.qtile, k, kprime, eps, out_scores, out_ids, out_counts, out_flags);
+    return launch_status();
+}
+
+extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,
+                                    int dim, const float* queries, int n_queries, void* workspace,
+                                    size_t workspace_bytes, thr_stream_t stream) {
+    THR_RETURN_IF(!docs || !inv_norm || !queries || !workspace, THR_ERR_INVALID);
+    THR_RETURN_IF(dim <= 0 || dim % CHUNK != 0 || dim / CHUNK > 4, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS || n_queries <= 0,
+                  THR_ERR_INVALID);
+    const DensePlan p = make_plan(n_docs, n_queries, 128);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
+    // tau is whatever the last thr_dense_topk on this workspace left (a realistic filter
+    // rate); the tile counters are reset so the lists never overflow across repeats
+    hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
+    if (e != hipSuccess) return (int)e;
+    return launch_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+                                    groups, 1, (const float*)(ws + p.off_tau),
+                                    (int*)(ws + p.off_tcnt), (Cand*)(ws + p.off_tlist), p.tile_cap,
+                                    nullptr, 0, st);
+}
+
+extern "C" size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries) {
+    (void)n_docs;
+    return (size_t)n_queries * EX_SLABS * THR_DENSE_MAX_K * (sizeof(double) + sizeof(int64_t));
+}
+
+extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int64_t n_docs, int dim,
+                                    int64_t id_base, const float* queries, int n_queries, int k,
+                                    double* out_scores, int64_t* out_ids, int32_t* out_counts,
+                                    uint32_t* out_flags, void* workspace, size_t workspace_bytes,
+                                    thr_stream_t stream) {
+    THR_RETURN_IF(!docs || !dnorm || !queries || !out_scores || !out_ids || !out_counts ||
+                      !out_flags || !workspace,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || k > THR_DENSE_MAX_K, THR_ERR_INVALID);
+    THR_RETURN_IF(dim <= 0 || dim % 4 != 0, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(workspace_bytes < thr_dense_exact_workspace_bytes(n_docs, n_queries),
+                  THR_ERR_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    double* slab_s = (double*)workspace;
+    int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
+    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
+                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, k, slab_s,
+                       slab_id);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
+                       (int64_t)EX_SLABS * k, (int64_t)k, EX_SLABS, k, k, id_base,
+                       THR_FLAG_CERTIFIED | THR_FLAG_EXACT, out_scores, out_ids, out_counts,
+                       out_flags);
+    return launch_status();
+}
+
+extern "C" int thr_merge_topk(const double* in_scores, const int64_t* in_ids, int n_queries,
+                              int n_lists, int k_in, int k_out, double* out_scores,
+                              int64_t* out_ids, int32_t* out_counts, thr_stream_t stream) {
+    THR_RETURN_IF(!in_scores || !in_ids || !out_scores || !out_ids, THR_ERR_INVALID);
+    THR_RETURN_IF(n_queries <= 0 || n_lists <= 0 || k_in <= 0 || k_out <= 0 || k_out > EX_CAP / 2,
+                  THR_ERR_INVALID);
+    // all-gather layout: [n_lists, n_queries, k_in]
+    hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, (hipStream_t)stream, in_scores,
+                       in_ids, (int64_t)k_in, (int64_t)n_queries * k_in, n_lists, k_in, k_out,
+                       (int64_t)0, 0u, out_scores, out_ids, out_counts, (uint32_t*)nullptr);
+    return launch_status();
+}

@@ -1,0 +1,268 @@
+// Graph channel: bounded BFS over the entity CSR + mention scoring (gfx950).
+//
+// Stands where the reference calls GraphSearcher.search
+// (src/voice_agent/rag2/retrieval.py:316-356 ->
+// src/voice_agent/rag2/graph_search.py:290-418).  The reference returns an
+// unordered set of chunk ids from PuppyGraph / SQL; the only score forms it
+// holds are the standalone package's Cypher, 1/(1+distance) over 1..N hops and
+// 1.0 for a direct mention (triple-hybrid-rag/src/triple_hybrid_rag/graph/
+// puppygraph.py:152-167, 203-221).  The contract implemented here is the
+// oracle's (oracle/thr_oracle.py graph_scores):
+//     score(c) = sum over reached entities e, ascending e, mentions in CSR order,
+//                of float64(conf(e,c)) / (1 + dist(e)),   dist(e) <= hops.
+//
+// One workgroup per query, everything on-chip except the contribution values:
+//   1. level-synchronous BFS with an LDS open-addressing set (entity -> dist)
+//   2. reached entities sorted ascending (LDS bitonic)
+//   3. one contribution per (entity, mention) at an exclusive-scan position, so
+//      position order == (entity asc, mention order)
+//   4. keys (local chunk << 32 | position) sorted in LDS; each chunk's segment is
+//      summed left to right in float64 by the thread that owns its head
+//   5. streaming block top-k under (score desc, chunk asc)
+// Algorithmic bytes per query: S*8 + sum_hops frontier*deg*4 + reached*(16 + mentions*8).
+#include "thr_common.hpp"
+
+namespace thr {
+
+constexpr int GR_THREADS = 256;
+constexpr int GR_SLOTS = 8192;     // hash slots (reached entities <= GR_MAX_ENT)
+constexpr int GR_MAX_ENT = 4096;
+constexpr int GR_MAX_CON = 8192;   // contributions per query
+constexpr int GR_CAP = 1024;       // BlockTopK buffer
+constexpr uint32_t GR_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t gr_hash(uint32_t e) { return (e * 2654435761u) >> 19; }  // 13 bits
+
+// insert entity e at BFS level `lvl`; returns true if newly inserted
+__device__ __forceinline__ bool gr_insert(uint32_t* keys, uint8_t* dist, uint32_t e, int lvl) {
+    uint32_t h = gr_hash(e) & (GR_SLOTS - 1);
+    for (int probe = 0; probe < GR_SLOTS; ++probe) {
+        uint32_t old = atomicCAS(&keys[h], GR_EMPTY, e);
+        if (old == GR_EMPTY) {
+            dist[h] = (uint8_t)lvl;
+            return true;
+        }
+        if (old == e) return false;
+        h = (h + 1) & (GR_SLOTS - 1);
+    }
+    return false;
+}
+
+// block-wide bitonic sort of uint64 keys, ascending, n = power of two
+__device__ inline void sort_u64_asc(uint64_t* a, int n) {
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                int p = i ^ j;
+                if (p > i) {
+                    bool up = (i & k) == 0;
+                    uint64_t x = a[i], y = a[p];
+                    if (up ? (x > y) : (x < y)) {
+                        a[i] = y;
+                        a[p] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
+    const int64_t* __restrict__ ent_rowptr, const int32_t* __restrict__ ent_col, int64_t n_entities,
+    const int64_t* __restrict__ men_rowptr, const int32_t* __restrict__ men_chunk,
+    const float* __restrict__ men_conf, int64_t chunk_base, int64_t n_chunks,
+    const int32_t* __restrict__ query_seeds, int max_seeds, int hops, int k,
+    double* __restrict__ con_val_ws,  // [nq][GR_MAX_CON]
+    double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt,
+    uint32_t* __restrict__ out_flags) {
+    // LDS: phase A (BFS) uses keys/dist/frontiers; phase B reuses the same bytes for sort keys
+    __shared__ uint64_t big[GR_MAX_CON];            // 64 KiB: hash set + lists, later sort keys
+    __shared__ uint32_t reached[GR_MAX_ENT];         // 16 KiB: (entity) list, later sorted
+    __shared__ uint8_t reached_dist[GR_MAX_ENT];     //  4 KiB
+    __shared__ int scan_tmp[GR_THREADS];
+    __shared__ double b_s[GR_CAP];
+    __shared__ int64_t b_id[GR_CAP];
+    __shared__ int b_cnt;
+    __shared__ double th_s;
+    __shared__ int64_t th_id;
+    __shared__ int n_reached, lvl_begin, lvl_end, overflow, n_con;
+
+    uint32_t* keys = reinterpret_cast<uint32_t*>(big);            // [GR_SLOTS]
+    uint8_t* hdist = reinterpret_cast<uint8_t*>(keys + GR_SLOTS);  // [GR_SLOTS]
+
+    const int q = blockIdx.x;
+    double* con_val = con_val_ws + (int64_t)q * GR_MAX_CON;
+    for (int i = threadIdx.x; i < GR_SLOTS; i += GR_THREADS) keys[i] = GR_EMPTY;
+    if (threadIdx.x == 0) {
+        n_reached = 0;
+        overflow = 0;
+        n_con = 0;
+    }
+    __syncthreads();
+
+    // ---- level 0: seeds ----
+    if (threadIdx.x < max_seeds) {
+        int32_t e = query_seeds[(int64_t)q * max_seeds + threadIdx.x];
+        if (e >= 0 && e < n_entities && gr_insert(keys, hdist, (uint32_t)e, 0)) {
+            int p = atomicAdd(&n_reached, 1);
+            reached[p] = (uint32_t)e;
+            reached_dist[p] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lvl_begin = 0;
+        lvl_end = n_reached;
+    }
+    __syncthreads();
+
+    // ---- BFS levels 1..hops: one wave per frontier entity, lanes over its edges ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = GR_THREADS / WAVE;
+    for (int lvl = 1; lvl <= hops; ++lvl) {
+        const int fb = lvl_begin, fe = lvl_end;
+        for (int f = fb + wave; f < fe; f += nw) {
+            const uint32_t e = reached[f];
+            const int64_t lo = ent_rowptr[e], hi = ent_rowptr[e + 1];
+            for (int64_t j = lo + lane; j < hi; j += WAVE) {
+                const int32_t t = ent_col[j];
+                if (t >= 0 && t < n_entities && gr_insert(keys, hdist, (uint32_t)t, lvl)) {
+                    int p = atomicAdd(&n_reached, 1);
+                    if (p < GR_MAX_ENT) {
+                        reached[p] = (uint32_t)t;
+                        reached_dist[p] = (uint8_t)lvl;
+                    } else {
+                        overflow = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            lvl_begin = fe;
+            lvl_end = n_reached < GR_MAX_ENT ? n_reached : GR_MAX_ENT;
+        }
+        __syncthreads();
+        if (overflow) break;
+    }
+    const int nr = n_reached < GR_MAX_ENT ? n_reached : GR_MAX_ENT;
+
+    // ---- sort reached entities ascending (key = entity << 8 | dist) ----
+    __syncthreads();
+    {
+        const int np = next_pow2(nr > 1 ? nr : 2);
+        for (int i = threadIdx.x; i < np; i += GR_THREADS)
+            big[i] = i < nr ? ((uint64_t)reached[i] << 8) | reached_dist[i] : ~0ull;
+        __syncthreads();
+        sort_u64_asc(big, np);
+        for (int i = threadIdx.x; i < nr; i += GR_THREADS) {
+            reached[i] = (uint32_t)(big[i] >> 8);
+            reached_dist[i] = (uint8_t)(big[i] & 0xff);
+        }
+        __syncthreads();
+    }
+
+    // ---- contributions: exclusive scan of mention counts over the sorted entities ----
+    int running = 0;  // same in every thread
+    for (int base = 0; base < nr; base += GR_THREADS) {
+        const int i = base + threadIdx.x;
+        int cntm = 0;
+        int64_t mlo = 0;
+        if (i < nr) {
+            mlo = men_rowptr[reached[i]];
+            cntm = (int)(men_rowptr[reached[i] + 1] - mlo);
+        }
+        scan_tmp[threadIdx.x] = cntm;
+        __syncthreads();
+        for (int off = 1; off < GR_THREADS; off <<= 1) {  // Hillis-Steele inclusive scan
+            int v = threadIdx.x >= off ? scan_tmp[threadIdx.x - off] : 0;
+            __syncthreads();
+            scan_tmp[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int excl = running + scan_tmp[threadIdx.x] - cntm;
+        const int chunk_total = scan_tmp[GR_THREADS - 1];
+        if (i < nr) {
+            const double w = __dadd_rn(1.0, (double)reached_dist[i]);
+            for (int m = 0; m < cntm; ++m) {
+                const int pos = excl + m;
+                if (pos < GR_MAX_CON) {
+                    const int64_t c = (int64_t)men_chunk[mlo + m] - chunk_base;
+                    const bool mine = c >= 0 && c < n_chunks;
+                    big[pos] = mine ? ((uint64_t)c << 32) | (uint32_t)pos : ~0ull;
+                    con_val[pos] = __ddiv_rn((double)men_conf[mlo + m], w);
+                } else {
+                    overflow = 1;
+                }
+            }
+        }
+        running += chunk_total;
+        __syncthreads();
+    }
+    const int nc = running < GR_MAX_CON ? running : GR_MAX_CON;
+    const int ncp = next_pow2(nc > 1 ? nc : 2);
+    for (int i = nc + threadIdx.x; i < ncp; i += GR_THREADS) big[i] = ~0ull;
+    __syncthreads();
+    sort_u64_asc(big, ncp);
+    __threadfence_block();
+
+    // ---- segmented left-to-right sums + top-k ----
+    BlockTopK<GR_CAP> tk;
+    tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);
+    for (int base = 0; base < nc; base += GR_THREADS) {
+        const int i = base + threadIdx.x;
+        bool head = false;
+        double score = 0.0;
+        int64_t chunk = 0;
+        if (i < nc && big[i] != ~0ull) {
+            const uint32_t c = (uint32_t)(big[i] >> 32);
+            head = (i == 0) || ((uint32_t)(big[i - 1] >> 32) != c);
+            if (head) {
+                chunk = c;
+                for (int j = i; j < nc && big[j] != ~0ull && (uint32_t)(big[j] >> 32) == c; ++j)
+                    score = __dadd_rn(score, con_val[(uint32_t)big[j]]);
+            }
+        }
+        tk.push(head, score, chunk);
+    }
+    const int n = tk.finish();
+    for (int i = threadIdx.x; i < k; i += GR_THREADS) {
+        out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
+        out_id[(int64_t)q * k + i] = i < n ? b_id[i] + chunk_base : -1;
+    }
+    if (threadIdx.x == 0) {
+        out_cnt[q] = n;
+        out_flags[q] = overflow ? THR_FLAG_OVERFLOW : THR_FLAG_CERTIFIED;
+    }
+}
+
+}  // namespace thr
+
+using namespace thr;
+
+extern "C" size_t thr_graph_workspace_bytes(int n_queries) {
+    return n_queries > 0 ? (size_t)n_queries * GR_MAX_CON * sizeof(double) : 0;
+}
+
+extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col, int64_t n_entities,
+                              const int64_t* men_rowptr, const int32_t* men_chunk,
+                              const float* men_conf, int64_t chunk_base, int64_t n_chunks,
+                              const int32_t* query_seeds, int n_queries, int max_seeds, int hops,
+                              int k, double* out_scores, int64_t* out_ids, int32_t* out_counts,
+                              uint32_t* out_flags, void* workspace, size_t workspace_bytes,
+                              thr_stream_t stream) {
+    THR_RETURN_IF(!ent_rowptr || !ent_col || !men_rowptr || !men_chunk || !men_conf ||
+                      !query_seeds || !out_scores || !out_ids || !out_counts || !out_flags ||
+                      !workspace,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_entities <= 0 || n_entities >= 0xffffffffll || n_chunks <= 0 ||
+                      n_chunks >= 0xffffffffll || n_queries <= 0 || max_seeds <= 0 ||
+                      max_seeds > THR_GRAPH_MAX_SEEDS || hops < 0 || hops > 8 || k <= 0 ||
+                      k > THR_TOPK_MAX,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(workspace_bytes < thr_graph_workspace_bytes(n_queries), THR_ERR_WORKSPACE);
+    hipLaunchKernelGGL(graph_topk_kernel, dim3(n_queries), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                       ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk, men_conf, chunk_base,
+                       n_chunks, query_seeds, max_seeds, hops, k, (double*)workspace, out_scores,
+                       out_ids, out_counts, out_flags);
+    return launch_status();
+}

@@ -1,0 +1,149 @@
+// Candidate merge + weighted Reciprocal Rank Fusion on the device (gfx950).
+//
+// Bit-for-bit the arithmetic and ordering of the reference's Python:
+//   RAG2Retriever._retrieve_candidates  src/voice_agent/rag2/retrieval.py:203-271
+//     1-based rank per channel; candidates in first-sighting order (lexical rows, then new
+//     semantic ids, then new graph ids); a duplicate id inside one channel keeps the LAST rank
+//   RAG2Retriever._fuse_rrf             src/voice_agent/rag2/retrieval.py:358-376
+//     score = 0.0 (+ w_l/(k+lr)) (+ w_s/(k+sr)) (+ w_g/(k+gr)) in float64, that add order;
+//     sorted(..., reverse=True) is stable, so ties keep the sighting order.
+// One workgroup per query; <= 3*128 candidates, all in LDS.  Host Python does the same for a
+// single query (rag2/retrieval.py of this package); this kernel exists because at ~1e5
+// queries/s a per-query Python loop would be the bottleneck of the batch path.
+#include "thr_common.hpp"
+
+namespace thr {
+
+constexpr int RRF_THREADS = 128;
+constexpr int RRF_MAXC = THR_RRF_MAX_PER_CHANNEL;  // per channel
+constexpr int RRF_SLOTS = 512;                      // >= 3 * RRF_MAXC, power of two
+
+// number of leading non-negative ids
+__device__ __forceinline__ int list_len(const int64_t* l, int n) {
+    int len = 0;
+    while (len < n && l[len] >= 0) ++len;
+    return len;
+}
+// last 1-based position of id in l[0..n), 0 if absent
+__device__ __forceinline__ int last_rank(const int64_t* l, int n, int64_t id) {
+    int r = 0;
+    for (int j = 0; j < n; ++j)
+        if (l[j] == id) r = j + 1;
+    return r;
+}
+__device__ __forceinline__ bool seen_before(const int64_t* l, int i, int64_t id) {
+    for (int j = 0; j < i; ++j)
+        if (l[j] == id) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(RRF_THREADS) void rrf_fuse_kernel(
+    const int64_t* __restrict__ lex, int n_lex, const int64_t* __restrict__ sem, int n_sem,
+    const int64_t* __restrict__ gra, int n_gra, double w_lex, double w_sem, double w_gra, int rrf_k,
+    int top_k, int64_t* __restrict__ out_ids, double* __restrict__ out_scores,
+    int32_t* __restrict__ out_ranks, int32_t* __restrict__ out_counts) {
+    __shared__ int64_t L[3][RRF_MAXC];
+    __shared__ int len[3];
+    __shared__ int is_new[3][RRF_MAXC];
+    __shared__ double s_s[RRF_SLOTS];
+    __shared__ int64_t s_pos[RRF_SLOTS];   // sighting position (sort tie-break), then payload index
+    __shared__ int64_t c_id[RRF_SLOTS];
+    __shared__ int c_rank[RRF_SLOTS][3];
+    __shared__ int n_cand;
+
+    const int q = blockIdx.x;
+    const int64_t* src[3] = {lex, sem, gra};
+    const int width[3] = {lex ? n_lex : 0, sem ? n_sem : 0, gra ? n_gra : 0};
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = threadIdx.x; i < RRF_MAXC; i += RRF_THREADS)
+            L[ch][i] = (i < width[ch]) ? src[ch][(int64_t)q * width[ch] + i] : -1;
+    for (int i = threadIdx.x; i < RRF_SLOTS; i += RRF_THREADS) {
+        s_s[i] = -INFINITY;
+        s_pos[i] = INT64_MAX;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) len[threadIdx.x] = list_len(L[threadIdx.x], width[threadIdx.x]);
+    __syncthreads();
+
+    // first sighting flags, channel by channel
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = threadIdx.x; i < RRF_MAXC; i += RRF_THREADS) {
+            bool nw = false;
+            if (i < len[ch]) {
+                const int64_t id = L[ch][i];
+                nw = !seen_before(L[ch], i, id);
+                for (int e = 0; e < ch && nw; ++e)
+                    if (last_rank(L[e], len[e], id)) nw = false;
+            }
+            is_new[ch][i] = nw ? 1 : 0;
+        }
+    __syncthreads();
+
+    // sighting position = number of new entries before (channel, i); score; stage for the sort
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = threadIdx.x; i < len[ch]; i += RRF_THREADS) {
+            if (!is_new[ch][i]) continue;
+            int pos = 0;
+            for (int e = 0; e < ch; ++e)
+                for (int j = 0; j < len[e]; ++j) pos += is_new[e][j];
+            for (int j = 0; j < i; ++j) pos += is_new[ch][j];
+            const int64_t id = L[ch][i];
+            const int lr = last_rank(L[0], len[0], id);
+            const int sr = last_rank(L[1], len[1], id);
+            const int gr = last_rank(L[2], len[2], id);
+            double score = 0.0;
+            if (lr) score = __dadd_rn(score, __ddiv_rn(w_lex, (double)(rrf_k + lr)));
+            if (sr) score = __dadd_rn(score, __ddiv_rn(w_sem, (double)(rrf_k + sr)));
+            if (gr) score = __dadd_rn(score, __ddiv_rn(w_gra, (double)(rrf_k + gr)));
+            c_id[pos] = id;
+            c_rank[pos][0] = lr;
+            c_rank[pos][1] = sr;
+            c_rank[pos][2] = gr;
+            s_s[pos] = score;
+            s_pos[pos] = pos;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int ch = 0; ch < 3; ++ch)
+            for (int j = 0; j < len[ch]; ++j) n += is_new[ch][j];
+        n_cand = n;
+    }
+    __syncthreads();
+    // (score desc, sighting position asc) is exactly Python's stable descending sort
+    bitonic_sort_desc<RRF_SLOTS>(s_s, s_pos);
+    const int n = n_cand;
+    for (int i = threadIdx.x; i < top_k; i += RRF_THREADS) {
+        const bool ok = i < n;
+        const int p = ok ? (int)s_pos[i] : 0;
+        out_ids[(int64_t)q * top_k + i] = ok ? c_id[p] : -1;
+        out_scores[(int64_t)q * top_k + i] = ok ? s_s[i] : -INFINITY;
+        if (out_ranks)
+            for (int c = 0; c < 3; ++c)
+                out_ranks[((int64_t)q * top_k + i) * 3 + c] = ok ? c_rank[p][c] : 0;
+    }
+    if (threadIdx.x == 0) out_counts[q] = n < top_k ? n : top_k;
+}
+
+}  // namespace thr
+
+using namespace thr;
+
+extern "C" int thr_rrf_fuse(const int64_t* lex_ids, int n_lex, const int64_t* sem_ids, int n_sem,
+                            const int64_t* graph_ids, int n_graph, int n_queries, double w_lex,
+                            double w_sem, double w_graph, int rrf_k, int top_k, int64_t* out_ids,
+                            double* out_scores, int32_t* out_ranks, int32_t* out_counts,
+                            thr_stream_t stream) {
+    THR_RETURN_IF(!out_ids || !out_scores || !out_counts, THR_ERR_INVALID);
+    THR_RETURN_IF(n_queries <= 0 || top_k <= 0 || top_k > RRF_SLOTS || rrf_k < 0, THR_ERR_INVALID);
+    THR_RETURN_IF(n_lex < 0 || n_sem < 0 || n_graph < 0 || n_lex > RRF_MAXC || n_sem > RRF_MAXC ||
+                      n_graph > RRF_MAXC,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF((!lex_ids || !n_lex) && (!sem_ids || !n_sem) && (!graph_ids || !n_graph),
+                  THR_ERR_INVALID);
+    hipLaunchKernelGGL(rrf_fuse_kernel, dim3(n_queries), dim3(RRF_THREADS), 0, (hipStream_t)stream,
+                       n_lex ? lex_ids : nullptr, n_lex, n_sem ? sem_ids : nullptr, n_sem,
+                       n_graph ? graph_ids : nullptr, n_graph, w_lex, w_sem, w_graph, rrf_k, top_k,
+                       out_ids, out_scores, out_ranks, out_counts);
+    return launch_status();
+}

@@ -1,0 +1,167 @@
+"""HBM-resident retrieval index and the batched device pipeline.
+
+``GpuIndex`` owns the tensors the HIP scorers read (one document shard per
+GPU) and exposes one method per channel plus ``retrieve_batch`` -- dense ->
+lexical -> graph -> weighted RRF (-> MaxSim rerank) with every stage a kernel
+behind the C ABI and no host round trip between stages.  The reference has no
+batch entry point (its ``retrieve()`` is one query per call,
+src/voice_agent/rag2/retrieval.py:118-201); the per-query drop-in sits on top
+of this in ``rag2/retrieval.py`` + ``backend.py``.
+
+Layout in HBM (per shard of n documents, D dims):
+    docs      float32 [n, D]   row-major, the only large array of the dense path
+    dnorm     float64 [n]      ||d||  (sequential float64, oracle contract)
+    inv_norm  float32 [n]      1/||d|| for the fp32 scan, 0 = no embedding
+    lexical   CSR by term: rowptr int64 [V+1], post_doc int32, post_tf int32,
+              doclen float32 [n], idf float64 [V] (global), avgdl (global)
+    graph     entity CSR (replicated) + entity->chunk mention CSR (this shard's chunks)
+    tokens    float16 [n, T_d, 128] late-interaction token matrices
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class BatchResult:
+    ids: torch.Tensor            # int64 [nq, top_k] fused (or reranked) global doc ids, -1 pad
+    scores: torch.Tensor         # float64 [nq, top_k] RRF scores (rerank: MaxSim scores)
+    counts: torch.Tensor         # int32 [nq]
+    channels: Dict[str, tuple] = field(default_factory=dict)  # name -> (scores, ids, counts)
+    rescued: int = 0             # queries that needed the exhaustive float64 path
+
+
+class GpuIndex:
+    def __init__(self, device: Optional[torch.device] = None, doc_base: int = 0):
+        if not torch.cuda.is_available():
+            raise N.NativeError("GpuIndex needs a HIP device (no CPU fallback exists)")
+        N.load()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.doc_base = int(doc_base)
+        self.n_docs = 0
+        self.dim = 0
+        self.docs = self.dnorm = self.inv_norm = None
+        self.lex = None
+        self.graph = None
+        self.tokens = None
+        self._ws: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------ builders
+    def _t(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    def set_dense(self, docs) -> "GpuIndex":
+        self.docs = self._t(docs, torch.float32)
+        self.n_docs, self.dim = self.docs.shape
+        self.dnorm, self.inv_norm = N.doc_norms(self.docs)
+        return self
+
+    def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
+                    k1: float = 1.2, b: float = 0.75) -> "GpuIndex":
+        self.lex = dict(rowptr=self._t(rowptr, torch.int64), post_doc=self._t(post_doc, torch.int32),
+                        post_tf=self._t(post_tf, torch.int32), doclen=self._t(doclen, torch.float32),
+                        idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b))
+        if self.n_docs == 0:
+            self.n_docs = int(self.lex["doclen"].shape[0])
+        return self
+
+    def set_graph(self, ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf) -> "GpuIndex":
+        self.graph = dict(ent_rowptr=self._t(ent_rowptr, torch.int64),
+                          ent_col=self._t(ent_col, torch.int32),
+                          men_rowptr=self._t(men_rowptr, torch.int64),
+                          men_chunk=self._t(men_chunk, torch.int32),
+                          men_conf=self._t(men_conf, torch.float32))
+        return self
+
+    def set_tokens(self, dtok) -> "GpuIndex":
+        self.tokens = self._t(dtok, torch.float16)
+        return self
+
+    # ------------------------------------------------------------ channels
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
+                     rescue: bool = True):
+        """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
+        fp32-error certificate cannot prove exact (massive ties / duplicates) are redone on
+        the exhaustive float64 path; that check reads the flags back (one sync per batch)."""
+        queries = self._t(queries, torch.float32)
+        kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
+        ws = self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
+        S, I, cnt, flg = N.dense_topk(self.docs, self.dnorm, self.inv_norm, queries, k, kp,
+                                      self.doc_base, ws)
+        n_rescued = 0
+        if rescue:
+            bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
+            n_rescued = int(bad.numel())
+            if n_rescued:
+                S2, I2, c2, _ = N.dense_topk_exact(self.docs, self.dnorm,
+                                                   queries[bad].contiguous(), k, self.doc_base)
+                S[bad], I[bad], cnt[bad] = S2, I2, c2
+        return S, I, cnt, n_rescued
+
+    def bm25_search(self, query_terms: torch.Tensor, k: int):
+        L = self.lex
+        return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
+                           L["avgdl"], self._t(query_terms, torch.int32), k, self.doc_base,
+                           L["k1"], L["b"])
+
+    def graph_search(self, query_seeds: torch.Tensor, k: int, hops: int = 2):
+        G = self.graph
+        S, I, cnt, flg = N.graph_topk(G["ent_rowptr"], G["ent_col"], G["men_rowptr"],
+                                      G["men_chunk"], G["men_conf"],
+                                      self._t(query_seeds, torch.int32), hops, k, self.doc_base,
+                                      self.n_docs)
+        if bool(((flg & N.THR_FLAG_OVERFLOW) != 0).any()):
+            raise N.NativeError("graph walk exceeded its on-chip capacity for some query")
+        return S, I, cnt
+
+    def maxsim(self, qtok: torch.Tensor, cand_global_ids: torch.Tensor) -> torch.Tensor:
+        """MaxSim of each query against its candidate docs (global ids; ids outside this
+        shard or negative score -inf)."""
+        local = cand_global_ids - self.doc_base
+        local = torch.where((local >= 0) & (local < self.tokens.shape[0]) & (cand_global_ids >= 0),
+                            local, torch.full_like(local, -1)).to(torch.int32).contiguous()
+        return N.maxsim(self._t(qtok, torch.float16), self.tokens, local)
+
+    # ------------------------------------------------------------ pipeline
+    def retrieve_batch(self, queries: torch.Tensor, query_terms: Optional[torch.Tensor] = None,
+                       query_seeds: Optional[torch.Tensor] = None, top_k: int = 10,
+                       semantic_top_k: int = 100, lexical_top_k: int = 50, graph_top_k: int = 50,
+                       weights: Optional[Dict[str, float]] = None, hops: int = 2,
+                       qtok: Optional[torch.Tensor] = None, rerank_top_k: int = 100,
+                       rescue: bool = True) -> BatchResult:
+        """plan.semantic/lexical/graph_top_k = 100/50/50 and weights 0.7/0.8/1.0 are the
+        reference's QueryPlan defaults (src/voice_agent/rag2/query_planner.py:23-50)."""
+        w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
+        w.update(weights or {})
+        ch = {}
+        Ss, Is, Cs, nres = self.dense_search(queries, semantic_top_k, rescue=rescue)
+        ch["semantic"] = (Ss, Is, Cs)
+        Il = Ig = None
+        if query_terms is not None and self.lex is not None:
+            Sl, Il, Cl = self.bm25_search(query_terms, lexical_top_k)
+            ch["lexical"] = (Sl, Il, Cl)
+        if query_seeds is not None and self.graph is not None:
+            Sg, Ig, Cg = self.graph_search(query_seeds, graph_top_k, hops)
+            ch["graph"] = (Sg, Ig, Cg)
+        n_fused = rerank_top_k if qtok is not None else top_k
+        ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, n_fused, w["lexical"], w["semantic"], w["graph"])
+        if qtok is not None and self.tokens is not None:
+            ms = self.maxsim(qtok, ids).to(torch.float64)
+            # stable descending sort on the rerank score (retrieval.py:455)
+            order = torch.sort(ms, dim=1, descending=True, stable=True).indices[:, :top_k]
+            ids, sc = torch.gather(ids, 1, order), torch.gather(ms, 1, order)
+            cnt = torch.clamp(cnt, max=top_k)
+        return BatchResult(ids, sc, cnt, ch, nres)
