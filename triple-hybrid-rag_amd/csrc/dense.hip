@@ -323,22 +323,45 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
     return prefix;
 }
 
-// K2: tau[q] = kk-th largest of sample_scores[q][0..n_sample)
-__global__ __launch_bounds__(256) void kth_select(const float* __restrict__ sample_scores,
-                                                  int64_t sample_ld, int n_sample, int kk,
-                                                  float* __restrict__ tau) {
-    __shared__ int hist[256];
-    __shared__ int bc[4];
-    const float* s = sample_scores + (int64_t)blockIdx.x * sample_ld;
-    int greater;
-    uint32_t key = block_radix_select([&](int i) { return fkey(s[i]); }, n_sample,
-                                      kk < n_sample ? kk : n_sample, hist, bc, &greater);
-    if (threadIdx.x == 0) tau[blockIdx.x] = n_sample >= kk ? fkey_inv(key) : -INFINITY;
+// true when the block's query is a padding row of its tile or an all-zero vector: such a query
+// must never emit (every row ties at 0 and would flood the tile's candidate list); a real zero
+// query therefore ends up uncertified and is answered by the exhaustive path.
+__device__ bool query_is_void(const float* __restrict__ queries, int n_queries, int dim, int q,
+                              int* flag) {
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    if (q < n_queries) {
+        int nz = 0;
+        for (int i = threadIdx.x; i < dim; i += blockDim.x) nz |= queries[(int64_t)q * dim + i] != 0.f;
+        if (nz) *flag = 1;
+    }
+    __syncthreads();
+    return *flag == 0;
 }
 
-__global__ void fill_f32(float* p, int n, float v) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+// K2: tau[q] = kk-th largest of sample_scores[q][0..n_sample)  (+inf for void queries;
+// n_sample == 0 means "no sample pass": tau = -inf, every row is a candidate)
+__global__ __launch_bounds__(256) void kth_select(const float* __restrict__ sample_scores,
+                                                  int64_t sample_ld, int n_sample, int kk,
+                                                  const float* __restrict__ queries, int n_queries,
+                                                  int dim, float* __restrict__ tau) {
+    __shared__ int hist[256];
+    __shared__ int bc[4];
+    __shared__ int flag;
+    const int q = blockIdx.x;
+    if (query_is_void(queries, n_queries, dim, q, &flag)) {
+        if (threadIdx.x == 0) tau[q] = INFINITY;
+        return;
+    }
+    if (n_sample < kk) {
+        if (threadIdx.x == 0) tau[q] = -INFINITY;
+        return;
+    }
+    const float* s = sample_scores + (int64_t)q * sample_ld;
+    int greater;
+    uint32_t key = block_radix_select([&](int i) { return fkey(s[i]); }, n_sample, kk, hist, bc,
+                                      &greater);
+    if (threadIdx.x == 0) tau[q] = fkey_inv(key);
 }
 
 // sequential float64 accumulation of float32 products: the oracle's contract
@@ -689,10 +712,10 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
                                    sample, p.sample_docs, st);
         if (rc) return rc;
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
-                           (int)p.sample_docs, kprime, tau);
+                           (int)p.sample_docs, kprime, queries, n_queries, dim, tau);
     } else {
-        hipLaunchKernelGGL(fill_f32, dim3((p.qpad + 255) / 256), dim3(256), 0, st, tau, p.qpad,
-                           -INFINITY);
+        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
+                           (int64_t)0, 0, kprime, queries, n_queries, dim, tau);
     }
     if ((rc = launch_status())) return rc;
     const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
