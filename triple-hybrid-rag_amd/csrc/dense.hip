@@ -17,6 +17,8 @@
 //                               with sequential accumulation (the oracle's contract), sort
 //                               (score desc, doc asc), certify with the fp32 error bound
 // Algorithmic HBM bytes of K3 = n_docs * dim * 4 per tile pass.
+#include <stdlib.h>
+
 #include "thr_common.hpp"
 
 namespace thr {
@@ -585,12 +587,21 @@ struct DensePlan {
     size_t off_tau, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, total;
 };
 
-constexpr int QT_DEFAULT = 32;
 constexpr int R_DEFAULT = 4;
+
+// queries per tile pass: 32 by default, THR_DENSE_QT=16 selects the half-size tile
+static int query_tile() {
+    static int qt = 0;
+    if (!qt) {
+        const char* e = getenv("THR_DENSE_QT");
+        qt = (e && atoi(e) == 16) ? 16 : 32;
+    }
+    return qt;
+}
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime) {
     DensePlan p;
-    p.qtile = QT_DEFAULT;
+    p.qtile = query_tile();
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
     const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
@@ -639,15 +650,17 @@ static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_
                        const float* queries, int n_queries, int ntiles, int64_t n_groups,
                        int64_t group_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                        int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    constexpr int QT = QT_DEFAULT, R = R_DEFAULT;
-    const size_t lds = sizeof(float) * QT * (size_t)dim + sizeof(Cand) * SCAN_WAVES * WBUF;
+    constexpr int R = R_DEFAULT;
+    const int qt = query_tile();
+    const size_t lds = sizeof(float) * qt * (size_t)dim + sizeof(Cand) * SCAN_WAVES * WBUF;
     int64_t waves = n_groups;
     int64_t blocks = (waves + SCAN_WAVES - 1) / SCAN_WAVES;
-    if (blocks > num_cus()) blocks = num_cus();  // one 512-thread block per CU (LDS-bound)
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;  // LDS-limited residency
+    if (blocks > (int64_t)num_cus() * per_cu) blocks = (int64_t)num_cus() * per_cu;
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, (unsigned)ntiles);
-#define THR_SCAN_CASE(NCH)                                                                        \
-    case NCH: {                                                                                   \
+#define THR_SCAN_LAUNCH(QT, NCH)                                                                  \
+    {                                                                                             \
         auto kern = dense_scan<QT, R, NCH, MODE, true>;                                           \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -655,8 +668,11 @@ static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_
         hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, docs, inv_norm, n_docs,       \
                            queries, n_queries, n_groups, group_stride, tau, tile_cnt, tile_list,  \
                            tile_cap, sample, sample_ld);                                          \
-        break;                                                                                    \
     }
+#define THR_SCAN_CASE(NCH)                                   \
+    case NCH:                                                \
+        if (qt == 16) THR_SCAN_LAUNCH(16, NCH) else THR_SCAN_LAUNCH(32, NCH) \
+        break;
     switch (dim / CHUNK) {
         THR_SCAN_CASE(1)
         THR_SCAN_CASE(2)
@@ -665,6 +681,7 @@ static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_
         default:
             return THR_ERR_UNSUPPORTED;
     }
+#undef THR_SCAN_LAUNCH
 #undef THR_SCAN_CASE
     return launch_status();
 }

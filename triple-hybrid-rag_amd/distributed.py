@@ -1,0 +1,78 @@
+"""Document-sharded retrieval across the GPUs of one node.
+
+One process per GPU.  Every channel's score for a document depends only on that
+document's row / postings / mentions plus query-global scalars, so the corpus is
+split into contiguous doc ranges [g*N/G, (g+1)*N/G); each rank produces its
+exact per-query top-k (global ids) and ONE exchange step per channel merges
+them: an all-gather of fixed-shape (score f64, id i64) tiles over RCCL/xGMI,
+then a merge kernel under (score desc, id asc).  Ranks (not scores) feed RRF,
+so the merge completes per channel before fusion.  The payload is KBs..MBs per
+batch, i.e. latency-bound on xGMI; the >=6x scaling comes from the 8x smaller
+per-GPU scan, not from the collective.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from .index import BatchResult, GpuIndex
+
+
+def shard_range(n_docs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous doc range of ``rank``: [lo, hi)."""
+    per = (n_docs + world - 1) // world
+    lo = min(n_docs, rank * per)
+    return lo, min(n_docs, lo + per)
+
+
+def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather each rank's [nq, k] (scores, ids) -> [world, nq, k] on every rank.
+    Backend-agnostic (RCCL on GPUs; gloo in the CPU tests)."""
+    world = dist.get_world_size(group)
+    S = torch.empty((world,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
+    I = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    if dist.get_backend(group) == "gloo":
+        dist.all_gather(list(S.unbind(0)), scores.contiguous(), group=group)
+        dist.all_gather(list(I.unbind(0)), ids.contiguous(), group=group)
+    else:
+        dist.all_gather_into_tensor(S, scores.contiguous(), group=group)
+        dist.all_gather_into_tensor(I, ids.contiguous(), group=group)
+    return S, I
+
+
+class ShardedIndex:
+    """A GpuIndex holding this rank's document shard + the cross-rank merge."""
+
+    def __init__(self, local: GpuIndex, group=None):
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _merge(self, S, I, k):
+        if self.world == 1:
+            return S, I
+        Sg, Ig = gather_topk(S, I, self.group)
+        Sm, Im, _ = N.merge_topk(Sg, Ig, k)
+        return Sm, Im
+
+    def retrieve_batch(self, queries, query_terms=None, query_seeds=None, top_k: int = 10,
+                       semantic_top_k: int = 100, lexical_top_k: int = 50, graph_top_k: int = 50,
+                       weights: Optional[Dict[str, float]] = None, hops: int = 2) -> BatchResult:
+        w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
+        w.update(weights or {})
+        L = self.local
+        Ss, Is, _, nres = L.dense_search(queries, semantic_top_k)
+        Ss, Is = self._merge(Ss, Is, semantic_top_k)
+        Il = Ig = None
+        if query_terms is not None and L.lex is not None:
+            Sl, Il, _ = L.bm25_search(query_terms, lexical_top_k)
+            Sl, Il = self._merge(Sl, Il, lexical_top_k)
+        if query_seeds is not None and L.graph is not None:
+            Sg, Ig, _ = L.graph_search(query_seeds, graph_top_k, hops)
+            Sg, Ig = self._merge(Sg, Ig, graph_top_k)
+        ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, top_k, w["lexical"], w["semantic"], w["graph"])
+        return BatchResult(ids, sc, cnt, {"semantic": (Ss, Is, None)}, nres)

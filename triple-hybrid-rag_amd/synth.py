@@ -8,6 +8,8 @@ the product path).
 """
 from __future__ import annotations
 
+import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -29,14 +31,15 @@ def _rng(*seed) -> np.random.Generator:
 
 
 def _normalize_rows_f32(x: np.ndarray) -> np.ndarray:
-    n = np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    n = np.sqrt(np.einsum("ij,ij->i", x, x, dtype=np.float32)).astype(np.float32)
     n[n == 0] = 1
-    return (x / n).astype(np.float32)
+    x /= n[:, None]
+    return x
 
 
 # ------------------------------------------------------------------ dense
 def dense_block(b: int, dim: int) -> np.ndarray:
-    x = _rng(SEED_DOCS, b).standard_normal((BLOCK, dim)).astype(np.float32)
+    x = _rng(SEED_DOCS, b).standard_normal((BLOCK, dim), dtype=np.float32)
     return _normalize_rows_f32(x)
 
 
@@ -44,18 +47,24 @@ def dense_rows(start: int, count: int, dim: int) -> np.ndarray:
     """Rows [start, start+count) of the global corpus."""
     out = np.empty((count, dim), dtype=np.float32)
     b0, b1 = start // BLOCK, (start + count - 1) // BLOCK
-    for b in range(b0, b1 + 1):
+
+    def fill(b):
         blk = dense_block(b, dim)
         lo = max(start, b * BLOCK)
         hi = min(start + count, (b + 1) * BLOCK)
         out[lo - start:hi - start] = blk[lo - b * BLOCK:hi - b * BLOCK]
+
+    # numpy's Generator releases the GIL while filling: blocks generate in parallel
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, b1 - b0 + 1)) as ex:
+        list(ex.map(fill, range(b0, b1 + 1)))
     return out
 
 
 def dense_queries(n_queries: int, dim: int, n_docs: int, noise: float = 0.5) -> np.ndarray:
-    """Half planted neighbours normalize(doc[j] + noise*g), half pure noise."""
+    """Half planted neighbours normalize(doc[j] + noise*g) with g a unit-norm noise vector
+    (cosine to the planted row ~ 1/sqrt(1+noise^2) = 0.894), half pure noise."""
     r = _rng(SEED_QUERIES)
-    g = r.standard_normal((n_queries, dim)).astype(np.float32)
+    g = _normalize_rows_f32(r.standard_normal((n_queries, dim), dtype=np.float32))
     planted = np.arange(n_queries) % 2 == 0
     j = r.integers(0, n_docs, size=n_queries)
     q = g.copy()
