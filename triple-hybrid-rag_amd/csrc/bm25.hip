@@ -158,6 +158,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                              double b, int64_t n_docs, int64_t id_base, const int32_t* query_terms,
                              int n_queries, int max_terms, int k, double* out_scores,
                              int64_t* out_ids, int32_t* out_counts, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !doclen || !idf || !query_terms ||
                       !out_scores || !out_ids || !out_counts,
                   THR_ERR_INVALID);

@@ -269,6 +269,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
     }
 }
 
+}  // namespace thr
+#include "dense_scan_mfma.hpp"
+namespace thr {
+
 // K3b: split a tile's mixed candidate list into the per-query lists K4 reads.
 __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__ tile_cnt,
                                                          const Cand* __restrict__ tile_list,
@@ -580,7 +584,8 @@ __global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in
 // host side
 // ---------------------------------------------------------------------------
 struct DensePlan {
-    int qtile, ntiles, qpad;
+    int qtile, ntiles, qpad, unit;
+    int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
     bool sampled;
     int tile_cap;
@@ -599,23 +604,45 @@ static int query_tile() {
     return qt;
 }
 
+// THR_DENSE_IMPL=valu selects the VALU scan (dense_scan<>); default is the fp32-MFMA scan
+static bool use_mfma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("THR_DENSE_IMPL");
+        v = (e && e[0] == 'v') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+// THR_DENSE_MFMA=1 selects the fragment-load MFMA scan, default 2 = LDS-transpose variant
+static int mfma_version() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("THR_DENSE_MFMA");
+        v = (e && atoi(e) == 1) ? 1 : 2;
+    }
+    return v;
+}
+
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime) {
     DensePlan p;
-    p.qtile = query_tile();
+    p.qtile = use_mfma() ? MF_QT : query_tile();
+    p.unit = use_mfma() ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
-    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
+    const int64_t groups = (n_docs + p.unit - 1) / p.unit;
     // sample only when the corpus is larger than what the candidate list can hold anyway
     p.sampled = n_docs > CAND_CAP / 2;
     int64_t target = n_docs / 32;
     if (target > SAMPLE_TARGET) target = SAMPLE_TARGET;
     if (target < 4 * (int64_t)kprime) target = 4 * (int64_t)kprime;
-    int64_t sg = (target + R_DEFAULT - 1) / R_DEFAULT;
+    int64_t sg = (target + p.unit - 1) / p.unit;
     if (sg > groups) sg = groups;
     p.sample_stride = sg > 0 ? groups / sg : 1;
     if (p.sample_stride < 1) p.sample_stride = 1;
     p.sample_groups = p.sampled ? sg : 0;
-    p.sample_docs = p.sample_groups * R_DEFAULT;
+    p.sample_docs = p.sample_groups * p.unit;
+    p.groups = groups;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -686,6 +713,64 @@ static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_
     return launch_status();
 }
 
+template <int MODE>
+static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
+                            const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
+                            int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
+                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
+    const size_t lds1 = sizeof(float) * MF_QT * (size_t)dim + sizeof(Cand) * MF_WAVES * WBUF;
+    const size_t lds2 = lds1 + sizeof(float4) * MF_WAVES * MF2_STAGE_F4;
+    // v2 needs 32 KiB of transpose tiles on top of the query tile: at dim 1024 that no longer
+    // fits the 160 KiB of a CU, and the fragment-load variant is used instead
+    const bool v2 = mfma_version() == 2 && lds2 <= 160 * 1024 && dim % 128 == 0;
+    const size_t lds = v2 ? lds2 : lds1;
+    int64_t blocks = (n_row_tiles + MF_WAVES - 1) / MF_WAVES;
+    if (blocks > num_cus()) blocks = num_cus();  // one block per CU: the query tile fills LDS
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, (unsigned)ntiles);
+#define THR_MF_CASE(D8)                                                                           \
+    case D8: {                                                                                    \
+        auto kern = v2 ? dense_scan_mfma2<D8, MODE> : dense_scan_mfma<D8, MODE>;                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(MF_THREADS), lds, st, docs, inv_norm, n_docs, queries, \
+                           n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
+                           tile_cap, sample, sample_ld);                                          \
+        break;                                                                                    \
+    }
+    switch (dim / 8) {
+        THR_MF_CASE(32)
+        THR_MF_CASE(64)
+        THR_MF_CASE(96)
+        THR_MF_CASE(128)
+        default:
+            return THR_ERR_UNSUPPORTED;
+    }
+#undef THR_MF_CASE
+    return launch_status();
+}
+
+template <int MODE>
+static int launch_any_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
+                           const float* queries, int n_queries, int ntiles, int64_t n_units,
+                           int64_t unit_stride, const float* tau, int* tile_cnt, Cand* tile_list,
+                           int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
+    if (use_mfma())
+        return launch_scan_mfma<MODE>(dim, docs, inv_norm, n_docs, queries, n_queries, ntiles,
+                                      n_units, unit_stride, tau, tile_cnt, tile_list, tile_cap,
+                                      sample, sample_ld, st);
+    return launch_scan<MODE>(dim, docs, inv_norm, n_docs, queries, n_queries, ntiles, n_units,
+                             unit_stride, tau, tile_cnt, tile_list, tile_cap, sample, sample_ld, st);
+}
+
+// fp32 error bound of the scan, relative to ||q||*||d||, in units of 2^-24:
+//   VALU: dim/64 chained FMAs per lane + 6 tree adds + 2 roundings; MFMA: a dim-long fma chain
+static double scan_eps(int dim) {
+    const double u = 5.9604644775390625e-08;
+    return use_mfma() ? ((double)dim + 16.0) * u : ((double)dim / 16.0 + 16.0) * u;
+}
+
 }  // namespace thr
 
 using namespace thr;
@@ -701,6 +786,7 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
                               int n_queries, int k, int kprime, double* out_scores,
                               int64_t* out_ids, int32_t* out_counts, uint32_t* out_flags,
                               void* workspace, size_t workspace_bytes, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!docs || !dnorm || !inv_norm || !queries || !out_scores || !out_ids ||
                       !out_counts || !out_flags || !workspace,
                   THR_ERR_INVALID);
@@ -724,9 +810,9 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
     if (e != hipSuccess) return (int)e;
     int rc;
     if (p.sampled) {
-        rc = launch_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
-                                   p.sample_groups, p.sample_stride, nullptr, nullptr, nullptr, 0,
-                                   sample, p.sample_docs, st);
+        rc = launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+                                       p.sample_groups, p.sample_stride, nullptr, nullptr, nullptr,
+                                       0, sample, p.sample_docs, st);
         if (rc) return rc;
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
                            (int)p.sample_docs, kprime, queries, n_queries, dim, tau);
@@ -735,15 +821,13 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
                            (int64_t)0, 0, kprime, queries, n_queries, dim, tau);
     }
     if ((rc = launch_status())) return rc;
-    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
-    rc = launch_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles, groups,
-                                  1, tau, tcnt, tlist, p.tile_cap, nullptr, 0, st);
+    rc = launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+                                      p.groups, 1, tau, tcnt, tlist, p.tile_cap, nullptr, 0, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bucket_candidates, dim3(64, p.ntiles), dim3(256), 0, st, tcnt, tlist,
                        p.tile_cap, p.qtile, cnt, cand);
     if ((rc = launch_status())) return rc;
-    // fp32 error bound of the scan: dim/64 chained FMAs per lane + 6 tree adds + 2 roundings
-    const double eps = ((double)dim / 16.0 + 16.0) * 5.9604644775390625e-08;
+    const double eps = scan_eps(dim);
     hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), sizeof(float) * dim, st,
                        docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
                        p.qtile, k, kprime, eps, out_scores, out_ids, out_counts, out_flags);
@@ -753,6 +837,7 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
 extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,
                                     int dim, const float* queries, int n_queries, void* workspace,
                                     size_t workspace_bytes, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!docs || !inv_norm || !queries || !workspace, THR_ERR_INVALID);
     THR_RETURN_IF(dim <= 0 || dim % CHUNK != 0 || dim / CHUNK > 4, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS || n_queries <= 0,
@@ -761,15 +846,14 @@ extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, in
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t groups = (n_docs + R_DEFAULT - 1) / R_DEFAULT;
     // tau is whatever the last thr_dense_topk on this workspace left (a realistic filter
     // rate); the tile counters are reset so the lists never overflow across repeats
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
-    return launch_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
-                                    groups, 1, (const float*)(ws + p.off_tau),
-                                    (int*)(ws + p.off_tcnt), (Cand*)(ws + p.off_tlist), p.tile_cap,
-                                    nullptr, 0, st);
+    return launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+                                        p.groups, 1, (const float*)(ws + p.off_tau),
+                                        (int*)(ws + p.off_tcnt), (Cand*)(ws + p.off_tlist),
+                                        p.tile_cap, nullptr, 0, st);
 }
 
 extern "C" size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries) {
@@ -782,6 +866,7 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
                                     double* out_scores, int64_t* out_ids, int32_t* out_counts,
                                     uint32_t* out_flags, void* workspace, size_t workspace_bytes,
                                     thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!docs || !dnorm || !queries || !out_scores || !out_ids || !out_counts ||
                       !out_flags || !workspace,
                   THR_ERR_INVALID);
@@ -807,6 +892,7 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
 extern "C" int thr_merge_topk(const double* in_scores, const int64_t* in_ids, int n_queries,
                               int n_lists, int k_in, int k_out, double* out_scores,
                               int64_t* out_ids, int32_t* out_counts, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!in_scores || !in_ids || !out_scores || !out_ids, THR_ERR_INVALID);
     THR_RETURN_IF(n_queries <= 0 || n_lists <= 0 || k_in <= 0 || k_out <= 0 || k_out > EX_CAP / 2,
                   THR_ERR_INVALID);

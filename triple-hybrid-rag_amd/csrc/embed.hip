@@ -53,6 +53,7 @@ using namespace thr;
 
 extern "C" int thr_embed_postproc(const float* full, int n, int full_dim, int store_dim, float* out,
                                   thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!full || !out || n <= 0 || full_dim <= 0 || store_dim <= 0, THR_ERR_INVALID);
     const int out_dim = full_dim < store_dim ? full_dim : store_dim;
     hipLaunchKernelGGL(embed_postproc, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, full, n,
@@ -62,6 +63,7 @@ extern "C" int thr_embed_postproc(const float* full, int n, int full_dim, int st
 
 extern "C" int thr_doc_norms(const float* docs, int64_t n_docs, int dim, double* dnorm,
                              float* inv_norm, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!docs || !dnorm || !inv_norm || n_docs <= 0, THR_ERR_INVALID);
     THR_RETURN_IF(dim <= 0 || dim % 4 != 0, THR_ERR_UNSUPPORTED);
     hipLaunchKernelGGL(doc_norms, dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0,

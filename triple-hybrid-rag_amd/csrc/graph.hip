@@ -250,6 +250,7 @@ extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col,
                               int k, double* out_scores, int64_t* out_ids, int32_t* out_counts,
                               uint32_t* out_flags, void* workspace, size_t workspace_bytes,
                               thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!ent_rowptr || !ent_col || !men_rowptr || !men_chunk || !men_conf ||
                       !query_seeds || !out_scores || !out_ids || !out_counts || !out_flags ||
                       !workspace,

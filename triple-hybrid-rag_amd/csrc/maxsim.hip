@@ -84,6 +84,7 @@ using namespace thr;
 extern "C" int thr_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, const uint16_t* dtok,
                           int64_t n_docs, int d_tokens, int tok_dim, const int32_t* cand, int n_cand,
                           float* out_scores, thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!qtok || !dtok || !cand || !out_scores, THR_ERR_INVALID);
     THR_RETURN_IF(n_queries <= 0 || n_docs <= 0 || n_cand <= 0, THR_ERR_INVALID);
     THR_RETURN_IF(q_tokens <= 0 || q_tokens % 32 || d_tokens <= 0 || d_tokens % 32 ||

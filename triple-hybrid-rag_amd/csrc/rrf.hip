@@ -134,6 +134,7 @@ extern "C" int thr_rrf_fuse(const int64_t* lex_ids, int n_lex, const int64_t* se
                             double w_sem, double w_graph, int rrf_k, int top_k, int64_t* out_ids,
                             double* out_scores, int32_t* out_ranks, int32_t* out_counts,
                             thr_stream_t stream) {
+    clear_status();
     THR_RETURN_IF(!out_ids || !out_scores || !out_counts, THR_ERR_INVALID);
     THR_RETURN_IF(n_queries <= 0 || top_k <= 0 || top_k > RRF_SLOTS || rrf_k < 0, THR_ERR_INVALID);
     THR_RETURN_IF(n_lex < 0 || n_sem < 0 || n_graph < 0 || n_lex > RRF_MAXC || n_sem > RRF_MAXC ||

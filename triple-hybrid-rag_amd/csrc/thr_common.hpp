@@ -15,6 +15,9 @@ constexpr int WAVE = 64;
         if (cond) return (code);  \
     } while (0)
 
+// entry points call this first: an earlier failed HIP call must not be reported as theirs
+inline void clear_status() { (void)hipGetLastError(); }
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? THR_OK : (int)e;
