@@ -187,8 +187,14 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
 //   fragment-shaped loads touch 16 lines per quarter-wave and are L1-tag-bound)
 //   -> register ring, 4 stages (16 KiB per wave) in flight -> ds_write_b128 into the
 //   wave's own [32 rows][32 dims] tile (XOR-swizzled) -> ds_read_b128 A fragments -> 16 MFMAs.
-// The tile is wave-private: no workgroup barrier anywhere in the loop.  The stage loop
-// runs in groups of 4 (= ring depth) so every register-array index is a constant.
+// The tile is wave-private: no workgroup barrier anywhere in the loop.  The loop is a
+// software pipeline over stages (32 dims each), continuous across row tiles:
+//     stage s:  MMA q0 | read q2 | MMA q1 | read q3 | write stage s+1 to LDS, refill its
+//               ring slot with stage s+5 | MMA q2 | read (s+1).q0 | MMA q3 | read (s+1).q1
+// LDS operations of one wave execute in order, so writing stage s+1 over the tile after the
+// last fragment reads of stage s have been ISSUED is safe, and every fragment is requested a
+// full MFMA quad (256 cycles) before it is used.  Stages run in groups of 4 (= ring depth)
+// so every register-array index is a constant.
 // ---------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: plain SSA loads/stores
 constexpr int MF2_AHEAD = 4;               // ring depth: stages (4 KiB each) in flight per wave
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     constexpr int D = D8 * 8;
     constexpr int CPR = D / 4;
     constexpr int NG = D / 128;  // groups of 4 stages of 32 dims
-    static_assert(D % 128 == 0, "dim must be a multiple of 128");
+    static_assert(D % 128 == 0 && NG >= 2, "dim must be a multiple of 128, >= 256");
     extern __shared__ float4 lds_q[];  // [32][CPR] queries | MF_WAVES stage tiles | MF_WAVES wbufs
 
     const int qtile = blockIdx.y;
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
         row = row < n_docs ? row : n_docs - 1;
         return row * CPR + lchunk;
     };
-    // LDS slots this lane writes (one per i) / reads as A fragment (one per jj); and the
-    // swizzled low part of the query-chunk index for (stage parity, jj)
+    // LDS slots this lane writes (one per i) / reads as A fragment (one per quad); and the
+    // swizzled low part of the query-chunk index for (stage parity, quad)
     int wslot0 = mf2_slot(lrow, lchunk), wslot1 = mf2_slot(lrow + 8, lchunk);
     int wslot2 = mf2_slot(lrow + 16, lchunk), wslot3 = mf2_slot(lrow + 24, lchunk);
     int rslot0 = mf2_slot(r, h), rslot1 = mf2_slot(r, 2 + h), rslot2 = mf2_slot(r, 4 + h),
@@ -263,47 +269,75 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     for (int x = 0; x < 8; ++x) qlow[x] = (((x >> 2) * 8 + 2 * (x & 3) + h) ^ r) & 15;
 
 #define THR_PIN(x) asm volatile("" : "+v"(x))
-#define MF2_LOAD(dst, base, stg)                 \
-    THR_PIN(base##0); dst[0] = docs4[base##0 + 8 * (stg)]; \
-    THR_PIN(base##1); dst[1] = docs4[base##1 + 8 * (stg)]; \
-    THR_PIN(base##2); dst[2] = docs4[base##2 + 8 * (stg)]; \
-    THR_PIN(base##3); dst[3] = docs4[base##3 + 8 * (stg)];
+    // request chunk-stage data of the 4 loader rows at the running pointers, then advance them
+#define MF2_LOAD(dst)                                       \
+    THR_PIN(p0); dst[0] = docs4[p0]; p0 += 8;               \
+    THR_PIN(p1); dst[1] = docs4[p1]; p1 += 8;               \
+    THR_PIN(p2); dst[2] = docs4[p2]; p2 += 8;               \
+    THR_PIN(p3); dst[3] = docs4[p3]; p3 += 8;
 #define MF2_STORE(src)                              \
     THR_PIN(wslot0); stage[wslot0] = src[0];        \
     THR_PIN(wslot1); stage[wslot1] = src[1];        \
     THR_PIN(wslot2); stage[wslot2] = src[2];        \
     THR_PIN(wslot3); stage[wslot3] = src[3];
-#define MF2_MMA(rs, ql, hi16)                                                     \
-    {                                                                             \
-        int qa = qbase + (hi16) + (ql);                                           \
-        THR_PIN(qa);                                                              \
-        const f32x4 bv = lds_v[qa];                                               \
-        THR_PIN(rs);                                                              \
-        const f32x4 av = stage[rs];                                               \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);     \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);     \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);     \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);     \
+    // Fragment reads are issued by inline asm and retired by hand-counted s_waitcnt: left to
+    // hipcc, each ds_read sinks down to its first use and the wave stalls a full LDS round trip
+    // before every MFMA quad.  "memory" clobbers keep hipcc's own LDS stores (the stage tile
+    // writes) and these reads in program order; the wait takes the fragments as in/out operands
+    // so the MFMAs that consume them cannot be hoisted above it.  LDS operations of one wave
+    // retire in order, so lgkmcnt(N) with N = LDS ops issued AFTER the wanted read is exact
+    // (anything else the compiler has in flight only makes the wait longer, never shorter).
+#define MF2_READ(fa, fb, rs, qb16, par, quad)                                             \
+    {                                                                                     \
+        const uint32_t qaddr = q_lds + (uint32_t)((qb16) + qlow[(par) * 4 + (quad)]) * 16u; \
+        const uint32_t aaddr = st_lds + (uint32_t)(rs) * 16u;                              \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb) : "v"(qaddr) : "memory");            \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa) : "v"(aaddr) : "memory");            \
     }
-    // one stage u (0..3) of group g: ring slot -> LDS, refill the slot, 16 MFMAs
-#define MF2_STAGE(ringu, u)                                                       \
-    MF2_STORE(ringu)                                                              \
-    MF2_LOAD(ringu, nb, u)                                                        \
-    MF2_MMA(rslot0, qlow[((u) & 1) * 4 + 0], ((u) >> 1) * 16)                     \
-    MF2_MMA(rslot1, qlow[((u) & 1) * 4 + 1], ((u) >> 1) * 16)                     \
-    MF2_MMA(rslot2, qlow[((u) & 1) * 4 + 2], ((u) >> 1) * 16)                     \
-    MF2_MMA(rslot3, qlow[((u) & 1) * 4 + 3], ((u) >> 1) * 16)                     \
+#define MF2_WAIT(n, fa, fb) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(fa), "+v"(fb) : : "memory");
+#define MF2_MMA(fa, fb)                                                           \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);         \
     asm volatile("" : "+v"(acc));
+    // stage u of a group: this stage's query chunks at qcur (parity u&1), the next stage's at
+    // qnxt (parity (u+1)&1); ringn = ring slot of stage s+1
+#define MF2_STAGE(u, ringn, qcur, qnxt)                                     \
+    MF2_WAIT(2, a0, b0) /* younger: the other pending fragment pair */      \
+    MF2_MMA(a0, b0)                                                         \
+    MF2_READ(a0, b0, rslot2, qcur, (u) & 1, 2)                              \
+    MF2_WAIT(2, a1, b1)                                                     \
+    MF2_MMA(a1, b1)                                                         \
+    MF2_READ(a1, b1, rslot3, qcur, (u) & 1, 3)                              \
+    MF2_STORE(ringn)                                                        \
+    MF2_LOAD(ringn)                                                         \
+    MF2_WAIT(6, a0, b0) /* younger: q3 pair + 4 stage-tile writes */        \
+    MF2_MMA(a0, b0)                                                         \
+    MF2_READ(a0, b0, rslot0, qnxt, ((u) + 1) & 1, 0)                        \
+    MF2_WAIT(6, a1, b1) /* younger: 4 stage-tile writes + next q0 pair */   \
+    MF2_MMA(a1, b1)                                                         \
+    MF2_READ(a1, b1, rslot1, qnxt, ((u) + 1) & 1, 1)
 
+    // LDS byte addresses for the asm reads
+    const uint32_t q_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_v;
+    const uint32_t st_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)stage;
     f32x4 ring0[4], ring1[4], ring2[4], ring3[4];
-    int64_t off0 = 0, off1 = 0, off2 = 0, off3 = 0;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int64_t t = wave_id;
+    const int qrow = r * CPR;
     if (t < n_tiles) {
-        off0 = load_off(t, 0); off1 = load_off(t, 1); off2 = load_off(t, 2); off3 = load_off(t, 3);
-        MF2_LOAD(ring0, off, 0)
-        MF2_LOAD(ring1, off, 1)
-        MF2_LOAD(ring2, off, 2)
-        MF2_LOAD(ring3, off, 3)
+        p0 = load_off(t, 0); p1 = load_off(t, 1); p2 = load_off(t, 2); p3 = load_off(t, 3);
+        MF2_LOAD(ring0)
+        MF2_LOAD(ring1)
+        MF2_LOAD(ring2)
+        MF2_LOAD(ring3)
+        MF2_STORE(ring0)   // stage 0 of the first tile
+        MF2_LOAD(ring0)    // <- stage 4
+        MF2_READ(a0, b0, rslot0, qrow, 0, 0)
+        MF2_READ(a1, b1, rslot1, qrow, 0, 1)
     }
     for (; t < n_tiles; t += wave_stride) {
         const int64_t row0 = t * tile_stride * MF_ROWS;
@@ -319,19 +353,16 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         for (int g = 0; g < NG; ++g) {
-            // refills of this group target the NEXT group's stages (or the next tile's head)
-            const bool last = g + 1 == NG;
-            int64_t nb0 = last ? on0 : off0 + 32 * (g + 1);
-            int64_t nb1 = last ? on1 : off1 + 32 * (g + 1);
-            int64_t nb2 = last ? on2 : off2 + 32 * (g + 1);
-            int64_t nb3 = last ? on3 : off3 + 32 * (g + 1);
-            const int qbase = r * CPR + 32 * g;
-            MF2_STAGE(ring0, 0)
-            MF2_STAGE(ring1, 1)
-            MF2_STAGE(ring2, 2)
-            MF2_STAGE(ring3, 3)
+            const int qb = qrow + 32 * g;                           // chunks of stages 4g, 4g+1
+            const int qn = g + 1 < NG ? qb + 32 : qrow;             // first chunks of the next group
+            MF2_STAGE(0, ring1, qb, qb)
+            MF2_STAGE(1, ring2, qb, qb + 16)
+            MF2_STAGE(2, ring3, qb + 16, qb + 16)
+            // the refill issued in the 4th stage is stage 4g+8: at g == NG-2 that is the head of
+            // the wave's NEXT row tile
+            if (g == NG - 2) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
+            MF2_STAGE(3, ring0, qb + 16, qn)
         }
-        off0 = on0; off1 = on1; off2 = on2; off3 = on3;
 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -358,6 +389,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     }
 #undef MF2_STAGE
 #undef MF2_MMA
+#undef MF2_READ
+#undef MF2_WAIT
 #undef MF2_STORE
 #undef MF2_LOAD
 #undef THR_PIN
