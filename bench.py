@@ -121,7 +121,8 @@ def main():
     tiles = (args.queries + qt - 1) // qt
     alg_bytes = tiles * n_local * args.dim * 4
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": f"dense_scan<QT={qt},R=4,MODE_FILTER>",
+    impl = "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2"
+    roofline = {"bound": "hbm", "kernel": f"{impl}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "launch_ms": round(scan_ms, 4), "tile_passes_per_launch": tiles,

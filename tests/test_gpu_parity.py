@@ -328,3 +328,81 @@ def test_full_size_1m_dense(T):
     Se, Ie, _ = CO.dense_topk_exact(x, q[sub], 100, dnorm=idx.dnorm.cpu().numpy())
     for j, qi in enumerate(sub):
         assert np.array_equal(I[qi], Ie[j]) and np.array_equal(S[qi], Se[j])
+
+
+def test_dropin_retrieve_end_to_end(T):
+    """The reference-shaped surface (RAG2Retriever.retrieve over GpuIndexClient) on a synthetic
+    corpus: contexts, ranks and RRF scores equal the CPU oracle pipeline."""
+    import asyncio
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    from triple_hybrid_rag_amd.config import SETTINGS
+    from triple_hybrid_rag_amd.rag2.embedder import PrecomputedEmbedder
+    from triple_hybrid_rag_amd.rag2.query_planner import QueryPlanner
+    from triple_hybrid_rag_amd.rag2.retrieval import RAG2Retriever
+
+    n, d = 20000, 768
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    g = synth.build_graph(n)
+    dtok = synth.doc_tokens(0, n, 32, 64)
+    idx = (T.GpuIndex().set_dense(x)
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf)
+           .set_tokens(dtok))
+    store = CorpusStore.synthetic(n, vocab_size=v, n_entities=synth.n_entities(n))
+
+    class TokEmb:
+        def embed_query_tokens(self, query):
+            return synth.query_tokens(1, 32, 64)[0]
+
+    client = GpuIndexClient(idx, store, org_id="org", token_embedder=TokEmb())
+    saved = dict(SETTINGS.__dict__)
+    SETTINGS.rag2_graph_enabled = True
+    SETTINGS.rag2_safety_threshold = 0.0
+    SETTINGS.rag2_denoise_alpha = 0.0
+    try:
+        rng = np.random.default_rng(12)
+        emb = PrecomputedEmbedder(store_dim=d)
+        qraw = synth.dense_queries(6, d, n)
+        for qi in range(6):
+            terms = [int(t) for t in rng.integers(50, v, 3)]
+            ents = [int(e) for e in rng.integers(0, synth.n_entities(n), 2)]
+            text = " ".join([f"t{t}" for t in terms] + [f"entity{e}" for e in ents])
+            raw = np.concatenate([qraw[qi] * 7.0, rng.standard_normal(300).astype(np.float32)])
+            emb.register(text, raw.tolist())
+            r = RAG2Retriever(org_id="org", embedder=emb, query_planner=QueryPlanner(graph=True),
+                              graph_enabled=True)
+            r._supabase = client
+            res = asyncio.run(r.retrieve(text, top_k=10, skip_rerank=True))
+            assert res.success and not res.refused and len(res.contexts) == 10
+            assert sorted(res.timings) == ["expansion", "fusion", "planning", "retrieval", "safety"]
+            # oracle pipeline
+            qv = np.asarray(emb.embed_query(text), dtype=np.float32)
+            _, Id, _ = CO.dense_topk_exact(x, qv[None], 100)
+            kw = text.split()
+            tids = [store.vocab[w] for w in kw if w in store.vocab]
+            _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [tids], n, 50)
+            seeds = client.find_entities(kw, 50)
+            _, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf,
+                                 [seeds], 2, n, 50)
+            ei, es = O.fused_topk_ids(list(Il[0]), list(Id[0]), list(Ig[0]), 10)
+            assert [c.child_id for c in res.contexts] == [f"c{i}" for i in ei]
+            assert [c.rrf_score for c in res.contexts] == es
+            assert all(c.parent_text == f"parent text {int(c.child_id[1:]) // 4}" for c in res.contexts)
+            # with the late-interaction reranker in the loop
+            res2 = asyncio.run(r.retrieve(text, top_k=5))
+            assert "rerank" in res2.timings and len(res2.contexts) <= 5
+            f20, _ = O.fused_topk_ids(list(Il[0]), list(Id[0]), list(Ig[0]), 20)
+            ms = CO.maxsim(synth.query_tokens(1, 32, 64), dtok, np.array([f20], dtype=np.int32))[0] / 32.0
+            got = {c.child_id: c.rerank_score for c in res2.contexts}
+            for cid, sc in got.items():
+                assert abs(sc - ms[f20.index(int(cid[1:]))]) < 1e-5
+            assert [c.rerank_score for c in res2.contexts] == sorted(got.values(), reverse=True)
+        # another tenant sees nothing
+        r = RAG2Retriever(org_id="other", embedder=emb, query_planner=QueryPlanner())
+        r._supabase = client
+        res = asyncio.run(r.retrieve(text, skip_planning=True, skip_rerank=True))
+        assert res.refused and res.refusal_reason == "No candidates found"
+    finally:
+        SETTINGS.__dict__.update(saved)

@@ -1,0 +1,257 @@
+"""Backend seam: a Supabase-shaped client answered by the GPU index.
+
+The reference's retriever talks to PostgREST through four calls (SURVEY.md
+section 8b; src/voice_agent/rag2/retrieval.py:282-290, 304-312, 339-341, 390-392):
+
+    client.rpc("rag2_lexical_search",  {p_org_id, p_query, p_limit, p_collection}).execute().data
+    client.rpc("rag2_semantic_search", {p_org_id, p_embedding, p_limit, p_collection}).execute().data
+    client.table("rag_child_chunks").select(...).in_("id", ids).execute().data
+    client.table("rag_parent_chunks").select(...).in_("id", ids).execute().data
+
+``GpuIndexClient`` offers exactly that duck type.  The two RPCs run the HIP
+scorers (thr_bm25_topk / thr_dense_topk + exhaustive rescue) on a ``GpuIndex``;
+the table fetches are answered from ``CorpusStore``, the host-side row payloads
+(ids, text, page, modality, parents) that the SQL rows would carry.
+Rows come back in REQUEST order from ``in_()`` (PostgreSQL's order there is
+unspecified; the reference ranks graph hits by that order, Appendix A.7).
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .index import GpuIndex
+
+_TOKEN = re.compile(r"[\w]+", re.UNICODE)
+
+
+def tokenize(text: str) -> List[str]:
+    """Lower-cased word tokens (the reference leaves tokenisation to PostgreSQL's
+    'portuguese' text-search configuration, which is not reproduced: no stemming)."""
+    return _TOKEN.findall(text.lower())
+
+
+@dataclass
+class CorpusStore:
+    child_ids: List[str]
+    parent_ids: List[str]
+    document_ids: List[str]
+    texts: List[str]
+    pages: List[int]
+    modalities: List[str]
+    parents: Dict[str, Dict[str, Any]] = field(default_factory=dict)  # id -> row
+    collections: Optional[List[Optional[str]]] = None
+    vocab: Dict[str, int] = field(default_factory=dict)               # term -> id
+    entity_names: List[str] = field(default_factory=list)
+    doc_base: int = 0
+
+    def __post_init__(self):
+        self._row_of = {cid: i for i, cid in enumerate(self.child_ids)}
+
+    def row_index(self, child_id: str) -> Optional[int]:
+        return self._row_of.get(child_id)
+
+    def child_row(self, i: int) -> Dict[str, Any]:
+        return {"id": self.child_ids[i], "parent_id": self.parent_ids[i],
+                "document_id": self.document_ids[i], "text": self.texts[i],
+                "page": self.pages[i], "modality": self.modalities[i]}
+
+    def result_row(self, i: int) -> Dict[str, Any]:
+        row = self.child_row(i)
+        row["child_id"] = row.pop("id")
+        return row
+
+    @classmethod
+    def synthetic(cls, n: int, doc_base: int = 0, children_per_parent: int = 4,
+                  vocab_size: int = 0, n_entities: int = 0) -> "CorpusStore":
+        """Row payloads for a synthetic corpus: ids derive from the global doc index."""
+        g = [doc_base + i for i in range(n)]
+        parents = {f"p{j}": {"id": f"p{j}", "text": f"parent text {j}",
+                             "section_heading": f"Section {j}"}
+                   for j in sorted({x // children_per_parent for x in g})}
+        return cls(child_ids=[f"c{x}" for x in g],
+                   parent_ids=[f"p{x // children_per_parent}" for x in g],
+                   document_ids=[f"d{x // 64}" for x in g], texts=[f"chunk {x}" for x in g],
+                   pages=[x % 9 + 1 for x in g], modalities=["text"] * n, parents=parents,
+                   vocab={f"t{t}": t for t in range(vocab_size)},
+                   entity_names=[f"entity{e}" for e in range(n_entities)], doc_base=doc_base)
+
+
+class _Reply:
+    def __init__(self, data):
+        self.data = data
+
+    def execute(self):
+        return self
+
+
+class _TableQuery:
+    def __init__(self, fetch):
+        self._fetch = fetch
+        self._ids: Optional[List[Any]] = None
+        self._limit: Optional[int] = None
+
+    def select(self, *_cols, **_kw):
+        return self
+
+    def eq(self, *_a, **_kw):
+        return self
+
+    def limit(self, n: int):
+        self._limit = n
+        return self
+
+    def in_(self, column: str, values: Sequence[Any]):
+        if column != "id":
+            raise ValueError("only id lookups are served from the GPU index store")
+        self._ids = list(values)
+        return self
+
+    def execute(self):
+        rows = self._fetch(self._ids or [])
+        return _Reply(rows[: self._limit] if self._limit is not None else rows)
+
+
+class GpuIndexClient:
+    """Supabase-shaped facade over (GpuIndex, CorpusStore)."""
+
+    def __init__(self, index: GpuIndex, store: CorpusStore, org_id: Optional[str] = None,
+                 token_embedder: Any = None):
+        self.index = index
+        self.store = store
+        self.org_id = org_id
+        self.token_embedder = token_embedder
+
+    # ---------------------------------------------------------------- RPCs
+    def rpc(self, name: str, params: Dict[str, Any]):
+        if self.org_id is not None and params.get("p_org_id") not in (None, self.org_id):
+            return _Reply([])  # data isolation: another tenant's index
+        if name == "rag2_semantic_search":
+            return _Reply(self._semantic(params["p_embedding"], int(params.get("p_limit", 100)),
+                                         params.get("p_collection")))
+        if name == "rag2_lexical_search":
+            return _Reply(self._lexical(params["p_query"], int(params.get("p_limit", 50)),
+                                        params.get("p_collection")))
+        raise ValueError(f"unknown RPC {name!r}")
+
+    def _rows(self, ids, scores, count, score_key, collection, limit):
+        out = []
+        for gid, sc in zip(ids[:count], scores[:count]):
+            i = int(gid) - self.store.doc_base
+            if collection is not None and self.store.collections is not None \
+                    and self.store.collections[i] != collection:
+                continue
+            row = self.store.result_row(i)
+            row[score_key] = float(sc)
+            out.append(row)
+            if len(out) == limit:
+                break
+        return out
+
+    def _semantic(self, embedding, limit: int, collection):
+        q = torch.tensor([list(map(float, embedding))], dtype=torch.float32,
+                         device=self.index.device)
+        if q.shape[1] != self.index.dim:
+            raise ValueError(f"embedding has {q.shape[1]} dims, index has {self.index.dim}")
+        k = min(N.THR_DENSE_MAX_K, limit if collection is None else 4 * limit)
+        S, I, cnt, _ = self.index.dense_search(q, k)
+        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "similarity", collection, limit)
+
+    def _lexical(self, query: str, limit: int, collection):
+        terms: List[int] = []
+        for tok in tokenize(query):
+            t = self.store.vocab.get(tok)
+            if t is not None and t not in terms:
+                terms.append(t)
+        if not terms or self.index.lex is None:
+            return []
+        terms = terms[: N.THR_BM25_MAX_TERMS]
+        qt = torch.tensor([terms], dtype=torch.int32, device=self.index.device)
+        k = min(N.THR_TOPK_MAX, limit if collection is None else 2 * limit)
+        S, I, cnt = self.index.bm25_search(qt, k)
+        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "rank", collection, limit)
+
+    # -------------------------------------------------------------- tables
+    def table(self, name: str) -> _TableQuery:
+        if name == "rag_child_chunks":
+            def fetch(ids):
+                rows = []
+                for cid in ids:
+                    i = self.store.row_index(cid)
+                    if i is not None:
+                        rows.append(self.store.child_row(i))
+                return rows
+            return _TableQuery(fetch)
+        if name == "rag_parent_chunks":
+            return _TableQuery(lambda ids: [dict(self.store.parents[p]) for p in ids
+                                            if p in self.store.parents])
+        raise ValueError(f"table {name!r} is not served by the GPU index")
+
+    # --------------------------------------------------------------- graph
+    def find_entities(self, keywords: List[str], limit: int = 20) -> List[int]:
+        """Entity ids whose name contains a keyword (ILIKE '%kw%'), at most 5 keywords and
+        limit // len(keywords) entities each (graph_search.py:161-170)."""
+        names = self.store.entity_names
+        if not keywords or not names:
+            return []
+        per = max(1, limit // len(keywords))
+        found: List[int] = []
+        for kw in keywords[:5]:
+            needle, hits = kw.lower(), 0
+            for e, name in enumerate(names):
+                if needle in name.lower():
+                    if e not in found:
+                        found.append(e)
+                    hits += 1
+                    if hits == per:
+                        break
+        return found[: N.THR_GRAPH_MAX_SEEDS]
+
+    def entity_name(self, e: int) -> str:
+        return self.store.entity_names[e]
+
+    def graph_chunks(self, seeds: List[int], top_k: int, hops: int = 2) -> List[str]:
+        pad = seeds + [-1] * (N.THR_GRAPH_MAX_SEEDS - len(seeds))
+        qs = torch.tensor([pad], dtype=torch.int32, device=self.index.device)
+        S, I, cnt = self.index.graph_search(qs, min(N.THR_TOPK_MAX, top_k), hops)
+        return [self.store.child_ids[int(g) - self.store.doc_base] for g in I[0, : int(cnt[0])].tolist()]
+
+    # -------------------------------------------------------------- rerank
+    def maxsim_scores(self, query: str, child_ids: List[str]) -> List[float]:
+        """MaxSim of the query's token matrix against the given chunks, divided by the number of
+        query tokens so unit-norm tokens give a [-1, 1] relevance like a cross-encoder's."""
+        if self.token_embedder is None or self.index.tokens is None:
+            raise RuntimeError("no token embedder / token store: late-interaction rerank unavailable")
+        qtok = np.asarray(self.token_embedder.embed_query_tokens(query), dtype=np.float16)[None]
+        ids = [self.store.row_index(c) for c in child_ids]
+        cand = torch.tensor([[self.store.doc_base + i if i is not None else -1 for i in ids]],
+                            dtype=torch.int64, device=self.index.device)
+        sc = self.index.maxsim(torch.from_numpy(qtok).to(self.index.device), cand)[0]
+        return [float(v) / qtok.shape[1] if np.isfinite(v) else 0.5 for v in sc.tolist()]
+
+    def text_to_child_id(self, text: str) -> Optional[str]:
+        if not hasattr(self, "_by_text"):
+            self._by_text = {t: c for t, c in zip(self.store.texts, self.store.child_ids)}
+            for pid, row in self.store.parents.items():
+                self._by_text.setdefault(row["text"], None)
+        return self._by_text.get(text)
+
+
+_default_client: Optional[GpuIndexClient] = None
+
+
+def set_default_client(client: Optional[GpuIndexClient]) -> None:
+    global _default_client
+    _default_client = client
+
+
+def get_supabase_client() -> GpuIndexClient:
+    """What ``RAG2Retriever.supabase`` resolves to (reference: utils/db.py:372-400)."""
+    if _default_client is None:
+        raise RuntimeError("no GPU index registered: call backend.set_default_client(...)")
+    return _default_client

@@ -1,0 +1,3 @@
+"""Standalone-package surface (drop-in for ``triple_hybrid_rag.core``)."""
+from .fusion import RRFFusion  # noqa: F401
+from .types import QueryPlan, SearchChannel, SearchResult  # noqa: F401

@@ -724,13 +724,19 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
     // fits the 160 KiB of a CU, and the fragment-load variant is used instead
     const bool v2 = mfma_version() == 2 && lds2 <= 160 * 1024 && dim % 128 == 0;
     const size_t lds = v2 ? lds2 : lds1;
+    static int nt = -1;  // THR_DENSE_NT=0 turns the non-temporal row loads off
+    if (nt < 0) {
+        const char* e = getenv("THR_DENSE_NT");
+        nt = (e && e[0] == '0') ? 0 : 1;
+    }
     int64_t blocks = (n_row_tiles + MF_WAVES - 1) / MF_WAVES;
     if (blocks > num_cus()) blocks = num_cus();  // one block per CU: the query tile fills LDS
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, (unsigned)ntiles);
 #define THR_MF_CASE(D8)                                                                           \
     case D8: {                                                                                    \
-        auto kern = v2 ? dense_scan_mfma2<D8, MODE> : dense_scan_mfma<D8, MODE>;                  \
+        auto kern = v2 ? (nt ? dense_scan_mfma2<D8, MODE, true> : dense_scan_mfma2<D8, MODE, false>) \
+                       : dense_scan_mfma<D8, MODE>;                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \

@@ -205,7 +205,7 @@ __device__ __forceinline__ int mf2_slot(int row, int chunk) {
     return row * 8 + (chunk ^ ((row >> 1) & 7));
 }
 
-template <int D8, int MODE>
+template <int D8, int MODE, bool nt_loads>
 __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     const float* __restrict__ docs, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
@@ -270,11 +270,13 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
 
 #define THR_PIN(x) asm volatile("" : "+v"(x))
     // request chunk-stage data of the 4 loader rows at the running pointers, then advance them
+    // (rows are read once per pass and never again by this CU: non-temporal loads)
+#define MF2_LD(ptr) (nt_loads ? __builtin_nontemporal_load(&docs4[ptr]) : docs4[ptr])
 #define MF2_LOAD(dst)                                       \
-    THR_PIN(p0); dst[0] = docs4[p0]; p0 += 8;               \
-    THR_PIN(p1); dst[1] = docs4[p1]; p1 += 8;               \
-    THR_PIN(p2); dst[2] = docs4[p2]; p2 += 8;               \
-    THR_PIN(p3); dst[3] = docs4[p3]; p3 += 8;
+    THR_PIN(p0); dst[0] = MF2_LD(p0); p0 += 8;              \
+    THR_PIN(p1); dst[1] = MF2_LD(p1); p1 += 8;              \
+    THR_PIN(p2); dst[2] = MF2_LD(p2); p2 += 8;              \
+    THR_PIN(p3); dst[3] = MF2_LD(p3); p3 += 8;
 #define MF2_STORE(src)                              \
     THR_PIN(wslot0); stage[wslot0] = src[0];        \
     THR_PIN(wslot1); stage[wslot1] = src[1];        \
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
 #undef MF2_WAIT
 #undef MF2_STORE
 #undef MF2_LOAD
+#undef MF2_LD
 #undef THR_PIN
     if constexpr (MODE == MODE_FILTER) {
         if (wcnt > 0) flush();

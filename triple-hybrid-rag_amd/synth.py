@@ -68,14 +68,11 @@ def dense_queries(n_queries: int, dim: int, n_docs: int, noise: float = 0.5) -> 
     planted = np.arange(n_queries) % 2 == 0
     j = r.integers(0, n_docs, size=n_queries)
     q = g.copy()
-    cache = {}
-    for i in np.nonzero(planted)[0]:
-        b = int(j[i]) // BLOCK
-        if b not in cache:
-            if len(cache) > 4:
-                cache.clear()
-            cache[b] = dense_block(b, dim)
-        q[i] = cache[b][int(j[i]) - b * BLOCK] + np.float32(noise) * g[i]
+    blocks = j // BLOCK
+    for b in np.unique(blocks[planted]):  # each needed block is generated once
+        blk = dense_block(int(b), dim)
+        sel = np.nonzero(planted & (blocks == b))[0]
+        q[sel] = blk[j[sel] - int(b) * BLOCK] + np.float32(noise) * g[sel]
     return _normalize_rows_f32(q)
 
 
