@@ -273,21 +273,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
 #include "dense_scan_mfma.hpp"
 namespace thr {
 
-// K3b: split a tile's mixed candidate list into the per-query lists K4 reads.
+// K3b: split a tile's mixed candidate list into the per-query lists K4 reads.  Each block
+// owns a contiguous slice of the list and reserves its output ranges with ONE global atomic
+// per query (counts first, in LDS), instead of one returning global atomic per entry.
+constexpr int BUCKET_BLOCKS = 32;
 __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__ tile_cnt,
                                                          const Cand* __restrict__ tile_list,
                                                          int tile_cap, int qtile,
                                                          int* __restrict__ cand_cnt,
                                                          Cand* __restrict__ cand) {
+    __shared__ int count[32], base[32], fill[32];
     const int tile = blockIdx.y;
     int n = tile_cnt[tile];
     n = n < tile_cap ? n : tile_cap;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     const Cand* list = tile_list + (int64_t)tile * tile_cap;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        Cand e = list[i];
-        const int q = tile * qtile + (int)(e.doc >> ROW_BITS);
-        const int p = atomicAdd(&cand_cnt[q], 1);
-        if (p < CAND_CAP) cand[(int64_t)q * CAND_CAP + p] = Cand{e.score, e.doc & ROW_MASK};
+    if (threadIdx.x < 32) count[threadIdx.x] = fill[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
+        atomicAdd(&count[list[i].doc >> ROW_BITS], 1);
+    __syncthreads();
+    if (threadIdx.x < qtile && count[threadIdx.x] > 0)
+        base[threadIdx.x] = atomicAdd(&cand_cnt[tile * qtile + threadIdx.x], count[threadIdx.x]);
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const Cand e = list[i];
+        const int ql = (int)(e.doc >> ROW_BITS);
+        const int p = base[ql] + atomicAdd(&fill[ql], 1);
+        if (p < CAND_CAP)
+            cand[(int64_t)(tile * qtile + ql) * CAND_CAP + p] = Cand{e.score, e.doc & ROW_MASK};
     }
 }
 
@@ -830,7 +845,7 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
     rc = launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
                                       p.groups, 1, tau, tcnt, tlist, p.tile_cap, nullptr, 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bucket_candidates, dim3(64, p.ntiles), dim3(256), 0, st, tcnt, tlist,
+    hipLaunchKernelGGL(bucket_candidates, dim3(BUCKET_BLOCKS, p.ntiles), dim3(256), 0, st, tcnt, tlist,
                        p.tile_cap, p.qtile, cnt, cand);
     if ((rc = launch_status())) return rc;
     const double eps = scan_eps(dim);
