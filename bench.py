@@ -122,9 +122,19 @@ def main():
     alg_bytes = tiles * n_local * args.dim * 4
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
     impl = "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2"
+    # HBM bytes from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per tile pass;
+    # only valid for the shape it was measured on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
+            pm = json.load(f)
+        if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt == 32:
+            traffic = round(pm["hbm_bytes_per_tile_pass"] * tiles)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": f"{impl}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "launch_ms": round(scan_ms, 4), "tile_passes_per_launch": tiles,
                 "algorithmic_bytes_per_launch": alg_bytes}
 
