@@ -734,32 +734,44 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
                             int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                             int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
     const size_t lds1 = sizeof(float) * MF_QT * (size_t)dim + sizeof(Cand) * MF_WAVES * WBUF;
-    const size_t lds2 = lds1 + sizeof(float4) * MF_WAVES * MF2_STAGE_F4;
-    // v2 needs 32 KiB of transpose tiles on top of the query tile: at dim 1024 that no longer
-    // fits the 160 KiB of a CU, and the fragment-load variant is used instead
-    const bool v2 = mfma_version() == 2 && lds2 <= 160 * 1024 && dim % 128 == 0;
-    const size_t lds = v2 ? lds2 : lds1;
+    auto lds2_for = [&](int nw) {
+        return sizeof(float) * MF_QT * (size_t)dim + (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * nw;
+    };
+    // v2 adds a 4 KiB transpose tile per wave on top of the query tile: 8 waves fit up to dim
+    // 768, 4 waves (one per SIMD) at dim 1024; otherwise the fragment-load variant runs
+    int nw = 0;
+    if (mfma_version() == 2 && dim % 128 == 0 && dim >= 256)
+        nw = lds2_for(8) <= 160 * 1024 ? 8 : (lds2_for(4) <= 160 * 1024 ? 4 : 0);
+    const bool v2 = nw != 0;
+    const size_t lds = v2 ? lds2_for(nw) : lds1;
     static int nt = -1;  // THR_DENSE_NT=0 turns the non-temporal row loads off
     if (nt < 0) {
         const char* e = getenv("THR_DENSE_NT");
         nt = (e && e[0] == '0') ? 0 : 1;
     }
-    int64_t blocks = (n_row_tiles + MF_WAVES - 1) / MF_WAVES;
+    const int waves = v2 ? nw : MF_WAVES;
+    int64_t blocks = (n_row_tiles + waves - 1) / waves;
     if (blocks > num_cus()) blocks = num_cus();  // one block per CU: the query tile fills LDS
     if (blocks < 1) blocks = 1;
     dim3 grid((unsigned)blocks, (unsigned)ntiles);
-#define THR_MF_CASE(D8)                                                                           \
-    case D8: {                                                                                    \
-        auto kern = v2 ? (nt ? dense_scan_mfma2<D8, MODE, true> : dense_scan_mfma2<D8, MODE, false>) \
-                       : dense_scan_mfma<D8, MODE>;                                               \
+#define THR_MF_LAUNCH(KERN, THREADS)                                                              \
+    {                                                                                             \
+        auto kern = KERN;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(MF_THREADS), lds, st, docs, inv_norm, n_docs, queries, \
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, docs, inv_norm, n_docs, queries,   \
                            n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
                            tile_cap, sample, sample_ld);                                          \
-        break;                                                                                    \
     }
+#define THR_MF_CASE(D8)                                                                           \
+    case D8:                                                                                      \
+        if (!v2) THR_MF_LAUNCH((dense_scan_mfma<D8, MODE>), MF_THREADS)                           \
+        else if (nw == 8 && nt) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, true, 8>), 512)         \
+        else if (nw == 8) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, false, 8>), 512)              \
+        else if (nt) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, true, 4>), 256)                    \
+        else THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, false, 4>), 256)                           \
+        break;
     switch (dim / 8) {
         THR_MF_CASE(32)
         THR_MF_CASE(64)
@@ -769,6 +781,7 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
             return THR_ERR_UNSUPPORTED;
     }
 #undef THR_MF_CASE
+#undef THR_MF_LAUNCH
     return launch_status();
 }
 

@@ -205,8 +205,8 @@ __device__ __forceinline__ int mf2_slot(int row, int chunk) {
     return row * 8 + (chunk ^ ((row >> 1) & 7));
 }
 
-template <int D8, int MODE, bool nt_loads>
-__global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
+template <int D8, int MODE, bool nt_loads, int NW>  // NW = waves per workgroup
+__global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
     const float* __restrict__ docs, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
     const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     constexpr int CPR = D / 4;
     constexpr int NG = D / 128;  // groups of 4 stages of 32 dims
     static_assert(D % 128 == 0 && NG >= 2, "dim must be a multiple of 128, >= 256");
-    extern __shared__ float4 lds_q[];  // [32][CPR] queries | MF_WAVES stage tiles | MF_WAVES wbufs
+    extern __shared__ float4 lds_q[];  // [32][CPR] queries | NW stage tiles | NW wbufs
 
     const int qtile = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     // memcpy out of a stack slot, which pins the whole register ring in scratch memory)
     f32x4* lds_v = reinterpret_cast<f32x4*>(lds_q);
     f32x4* stage = lds_v + MF_QT * CPR + wave * MF2_STAGE_F4;
-    Cand* wbuf = reinterpret_cast<Cand*>(lds_q + MF_QT * CPR + MF_WAVES * MF2_STAGE_F4) + wave * WBUF;
+    Cand* wbuf = reinterpret_cast<Cand*>(lds_q + MF_QT * CPR + NW * MF2_STAGE_F4) + wave * WBUF;
     int wcnt = 0;
     auto flush = [&]() {
         int base = 0;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
         wcnt = 0;
     };
 
-    for (int i = threadIdx.x; i < MF_QT * CPR; i += MF_THREADS) {
+    for (int i = threadIdx.x; i < MF_QT * CPR; i += (NW * WAVE)) {
         const int q = i / CPR, c = i % CPR;
         const int qg = qtile * MF_QT + q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma2(
     __syncthreads();
 
     const float my_tau = MODE == MODE_FILTER ? tau[qtile * MF_QT + r] : 0.f;
-    const int64_t wave_id = (int64_t)blockIdx.x * MF_WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * MF_WAVES;
+    const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * NW;
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
 
     // loader role of this lane: row (lane >> 3) + 8*i of the tile, 16-byte chunk (lane & 7)
