@@ -738,10 +738,11 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
         return sizeof(float) * MF_QT * (size_t)dim + (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * nw;
     };
     // v2 adds a 4 KiB transpose tile per wave on top of the query tile: 8 waves fit up to dim
-    // 768, 4 waves (one per SIMD) at dim 1024; otherwise the fragment-load variant runs
+    // 768.  At dim 1024 only 4 waves (one per SIMD) would fit, and that measured slower than
+    // the fragment-load variant with 8 waves (4.30 vs 4.93 TB/s), which therefore runs there.
     int nw = 0;
     if (mfma_version() == 2 && dim % 128 == 0 && dim >= 256)
-        nw = lds2_for(8) <= 160 * 1024 ? 8 : (lds2_for(4) <= 160 * 1024 ? 4 : 0);
+        nw = lds2_for(8) <= 160 * 1024 ? 8 : 0;
     const bool v2 = nw != 0;
     const size_t lds = v2 ? lds2_for(nw) : lds1;
     static int nt = -1;  // THR_DENSE_NT=0 turns the non-temporal row loads off
@@ -767,10 +768,8 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
 #define THR_MF_CASE(D8)                                                                           \
     case D8:                                                                                      \
         if (!v2) THR_MF_LAUNCH((dense_scan_mfma<D8, MODE>), MF_THREADS)                           \
-        else if (nw == 8 && nt) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, true, 8>), 512)         \
-        else if (nw == 8) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, false, 8>), 512)              \
-        else if (nt) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, true, 4>), 256)                    \
-        else THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, false, 4>), 256)                           \
+        else if (nt) THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, true, 8>), 512)                    \
+        else THR_MF_LAUNCH((dense_scan_mfma2<D8, MODE, false, 8>), 512)                           \
         break;
     switch (dim / 8) {
         THR_MF_CASE(32)
