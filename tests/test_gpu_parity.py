@@ -406,3 +406,32 @@ def test_dropin_retrieve_end_to_end(T):
         assert res.refused and res.refusal_reason == "No candidates found"
     finally:
         SETTINGS.__dict__.update(saved)
+
+
+@pytest.mark.parametrize("n,d", [(50000, 768), (20000, 1024), (4000, 512)])
+def test_dense_f16_shortlist_is_still_exact(T, n, d):
+    """Opt-in float16 shortlist copy: results must be the SAME bits as the float32 oracle
+    (scores come from float64 rescoring of float32 rows; the certificate covers quantisation)."""
+    x, rng = rand_docs(n, d, 77)
+    x[13] = 0
+    x[200:230] = x[199]                      # 31-way tie inside the top-100 of query 0
+    q = rng.standard_normal((70, d)).astype(np.float32)
+    q[0] = x[199] + 0.05 * q[0]
+    q[::2] = x[rng.integers(0, n, 35)] + 0.5 * q[::2]
+    q[5] = 0
+    idx = T.GpuIndex(doc_base=123).set_dense(x, shortlist="f16")
+    assert 0 < idx.doc_rel_err < 6e-4        # ~2^-12/sqrt(3) typical, 2^-11 worst case
+    x16 = idx.docs16.cpu().numpy()
+    assert np.array_equal(x16, x.astype(np.float16))
+    nz = x.any(axis=1)
+    rel = (np.linalg.norm(x16.astype(np.float64) - x, axis=1)[nz]
+           / np.linalg.norm(x.astype(np.float64), axis=1)[nz])
+    assert rel.max() <= idx.doc_rel_err
+    S, I, cnt, flg = T._native.dense_topk_f16(idx.docs, idx.docs16, idx.doc_rel_err, idx.dnorm,
+                                              idx.inv_norm, dev(q), 100, 256, 123)
+    flags = flg.cpu().numpy()
+    assert flags[5] & 1 == 0                 # zero query is never certified
+    assert np.mean(flags & 1) > 0.9          # random data certifies through the f16 bound
+    S, I, cnt, nres = idx.dense_search(dev(q), 100)
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 100, doc_id_base=123)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "dense-f16")

@@ -47,6 +47,11 @@ _SIGNATURES = {
     "thr_dense_topk_exact": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
                                     _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "thr_dense_quantize_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
+                                  _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
                              _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32]),
@@ -211,6 +216,62 @@ def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
     _check(load().thr_dense_scan_probe(pd, pi, n, d, pq, queries.shape[0], pw,
                                        workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_scan_probe")
+
+
+def dense_quantize_f16(docs: torch.Tensor):
+    """-> (docs16 f16 [n, D], max relative row error as a Python float)."""
+    p = _dev(docs, torch.float32, "docs", 2)
+    n, d = docs.shape
+    d16 = torch.empty((n, d), dtype=torch.float16, device=docs.device)
+    err = torch.zeros(1, dtype=torch.float32, device=docs.device)
+    _check(load().thr_dense_quantize_f16(p, n, d, d16.data_ptr(), err.data_ptr(), _stream()),
+           "thr_dense_quantize_f16")
+    return d16, float(err.item())
+
+
+def dense_f16_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int) -> int:
+    return int(load().thr_dense_f16_workspace_bytes(n_docs, dim, n_queries, kprime))
+
+
+def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k: int,
+                   kprime: int, id_base: int = 0, workspace: Optional[torch.Tensor] = None):
+    pd = _dev(docs, torch.float32, "docs", 2)
+    ph = _dev(docs16, torch.float16, "docs16", 2)
+    n, d = docs.shape
+    if tuple(docs16.shape) != (n, d):
+        raise NativeError("docs16 shape != docs shape")
+    pq = _dev(queries, torch.float32, "queries", 2)
+    nq = queries.shape[0]
+    if queries.shape[1] != d:
+        raise NativeError(f"queries dim {queries.shape[1]} != docs dim {d}")
+    pn = _dev(dnorm, torch.float64, "dnorm", 1)
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    if dnorm.shape[0] != n or inv_norm.shape[0] != n:
+        raise NativeError("dnorm / inv_norm length != n_docs")
+    need = dense_f16_workspace_bytes(n, d, nq, kprime)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    S, I, cnt, flg = _alloc_out(nq, k, docs.device)
+    _check(load().thr_dense_topk_f16(pd, ph, float(doc_rel_err), pn, pi, n, d, id_base, pq, nq, k,
+                                     kprime, S.data_ptr(), I.data_ptr(), cnt.data_ptr(),
+                                     flg.data_ptr(), pw,
+                                     workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_topk_f16")
+    return S, I, cnt, flg
+
+
+def dense_scan_probe_f16(docs16, inv_norm, queries, workspace: torch.Tensor) -> None:
+    ph = _dev(docs16, torch.float16, "docs16", 2)
+    n, d = docs16.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    if queries.shape[1] != d or inv_norm.shape[0] != n:
+        raise NativeError("probe: shape mismatch")
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    _check(load().thr_dense_scan_probe_f16(ph, pi, n, d, pq, queries.shape[0], pw,
+                                           workspace.numel() * workspace.element_size(),
+                                           _stream()), "thr_dense_scan_probe_f16")
 
 
 # --------------------------------------------------------------------- a3

@@ -32,6 +32,7 @@ constexpr int SAMPLE_TARGET = 32768;       // sample docs for the tau estimate
 constexpr int WBUF = 256;                  // per-wave LDS staging slots for passing rows
 constexpr int ROW_BITS = 27;               // tile-list entries pack (query-in-tile << 27 | row)
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
+constexpr int ROW_BITS_F16 = 26;           // f16 shortlist scan: 64 queries per tile -> 6 bits
 
 struct Cand {
     float score;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
 
 }  // namespace thr
 #include "dense_scan_mfma.hpp"
+#include "dense_scan_f16.hpp"
 namespace thr {
 
 // K3b: split a tile's mixed candidate list into the per-query lists K4 reads.  Each block
@@ -279,30 +281,31 @@ namespace thr {
 constexpr int BUCKET_BLOCKS = 32;
 __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__ tile_cnt,
                                                          const Cand* __restrict__ tile_list,
-                                                         int tile_cap, int qtile,
+                                                         int tile_cap, int qtile, int row_bits,
                                                          int* __restrict__ cand_cnt,
                                                          Cand* __restrict__ cand) {
-    __shared__ int count[32], base[32], fill[32];
+    __shared__ int count[64], base[64], fill[64];
+    const uint32_t row_mask = (1u << row_bits) - 1u;
     const int tile = blockIdx.y;
     int n = tile_cnt[tile];
     n = n < tile_cap ? n : tile_cap;
     const int per = (n + gridDim.x - 1) / gridDim.x;
     const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     const Cand* list = tile_list + (int64_t)tile * tile_cap;
-    if (threadIdx.x < 32) count[threadIdx.x] = fill[threadIdx.x] = 0;
+    if (threadIdx.x < 64) count[threadIdx.x] = fill[threadIdx.x] = 0;
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
-        atomicAdd(&count[list[i].doc >> ROW_BITS], 1);
+        atomicAdd(&count[list[i].doc >> row_bits], 1);
     __syncthreads();
     if (threadIdx.x < qtile && count[threadIdx.x] > 0)
         base[threadIdx.x] = atomicAdd(&cand_cnt[tile * qtile + threadIdx.x], count[threadIdx.x]);
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const Cand e = list[i];
-        const int ql = (int)(e.doc >> ROW_BITS);
+        const int ql = (int)(e.doc >> row_bits);
         const int p = base[ql] + atomicAdd(&fill[ql], 1);
         if (p < CAND_CAP)
-            cand[(int64_t)(tile * qtile + ql) * CAND_CAP + p] = Cand{e.score, e.doc & ROW_MASK};
+            cand[(int64_t)(tile * qtile + ql) * CAND_CAP + p] = Cand{e.score, e.doc & row_mask};
     }
 }
 
@@ -365,11 +368,38 @@ __device__ bool query_is_void(const float* __restrict__ queries, int n_queries, 
 __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ sample_scores,
                                                   int64_t sample_ld, int n_sample, int kk,
                                                   const float* __restrict__ queries, int n_queries,
-                                                  int dim, float* __restrict__ tau) {
+                                                  int dim, float* __restrict__ tau,
+                                                  float* __restrict__ qerr) {
     __shared__ int hist[256];
     __shared__ int bc[4];
     __shared__ int flag;
+    __shared__ double red[2][256];
     const int q = blockIdx.x;
+    if (qerr) {
+        // eq = ||fp16(q) - q|| / ||q||, rounded up: the query-side term of the f16 certificate
+        double e = 0.0, nn = 0.0;
+        if (q < n_queries)
+            for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+                const float v = queries[(int64_t)q * dim + i];
+                const double dd = (double)v - (double)(float)(_Float16)v;
+                e += dd * dd;
+                nn += (double)v * (double)v;
+            }
+        red[0][threadIdx.x] = e;
+        red[1][threadIdx.x] = nn;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + o];
+                red[1][threadIdx.x] += red[1][threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            float rel = red[1][0] > 0.0 ? (float)sqrt(red[0][0] / red[1][0]) : 0.f;
+            qerr[q] = __uint_as_float(__float_as_uint(rel) + 1u);
+        }
+    }
     if (query_is_void(queries, n_queries, dim, q, &flag)) {
         if (threadIdx.x == 0) tau[q] = INFINITY;
         return;
@@ -406,8 +436,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
     const float* __restrict__ queries, const float* __restrict__ tau,
     const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
-    const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps,
-    double* __restrict__ out_scores, int64_t* __restrict__ out_ids,
+    const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
+    double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores, int64_t* __restrict__ out_ids,
     int32_t* __restrict__ out_counts, uint32_t* __restrict__ out_flags) {
     extern __shared__ float lds_qv[];  // [dim] query
     __shared__ int hist[256];
@@ -418,6 +448,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     __shared__ double s_qn;
 
     const int q = blockIdx.x;
+    // scan error bound relative to ||q||*||d||: fp32 accumulation, plus -- for the float16
+    // shortlist copy -- row and query quantisation: ea*(1+eq) + eq
+    const double eq = qerr ? (double)qerr[q] : 0.0;
+    const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
     const Cand* c = cand + (int64_t)q * CAND_CAP;
     const int cnt = cand_cnt[q];
     const bool overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
@@ -599,12 +633,12 @@ __global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in
 // host side
 // ---------------------------------------------------------------------------
 struct DensePlan {
-    int qtile, ntiles, qpad, unit;
+    int qtile, ntiles, qpad, unit, kind, row_bits;
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
     bool sampled;
     int tile_cap;
-    size_t off_tau, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, total;
+    size_t off_tau, off_qerr, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, total;
 };
 
 constexpr int R_DEFAULT = 4;
@@ -639,10 +673,15 @@ static int mfma_version() {
     return v;
 }
 
-static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime) {
+constexpr int KIND_F32 = 0, KIND_F16 = 1;
+constexpr int F16_NQ = 2;  // 64 queries per tile pass on the float16 copy
+
+static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32) {
     DensePlan p;
-    p.qtile = use_mfma() ? MF_QT : query_tile();
-    p.unit = use_mfma() ? MF_ROWS : R_DEFAULT;
+    p.kind = kind;
+    p.row_bits = kind == KIND_F16 ? ROW_BITS_F16 : ROW_BITS;
+    p.qtile = kind == KIND_F16 ? 32 * F16_NQ : (use_mfma() ? MF_QT : query_tile());
+    p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
     const int64_t groups = (n_docs + p.unit - 1) / p.unit;
@@ -665,6 +704,7 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime) {
         return o;
     };
     p.off_tau = take(sizeof(float) * p.qpad);
+    p.off_qerr = take(sizeof(float) * p.qpad);
     p.tile_cap = p.qtile * (CAND_CAP / 2);
     p.off_cnt = take(sizeof(int) * p.qpad);   // off_cnt and off_tcnt are zeroed by one memset
     p.off_tcnt = take(sizeof(int) * p.ntiles);
@@ -785,6 +825,40 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
 }
 
 template <int MODE>
+static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_norm, int64_t n_docs,
+                           const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
+                           int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
+                           int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
+    const size_t lds = sizeof(_Float16) * 32 * F16_NQ * (size_t)dim +
+                       (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES;
+    THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
+    int64_t blocks = (n_row_tiles + H_WAVES - 1) / H_WAVES;
+    if (blocks > num_cus()) blocks = num_cus();
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks, (unsigned)ntiles);
+#define THR_H_CASE(DIM)                                                                           \
+    case DIM: {                                                                                   \
+        auto kern = dense_scan_f16<DIM, MODE, true, F16_NQ>;                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, docs16, inv_norm, n_docs,        \
+                           queries, n_queries, n_row_tiles, tile_stride, tau, tile_cnt,           \
+                           tile_list, tile_cap, sample, sample_ld);                               \
+        break;                                                                                    \
+    }
+    switch (dim) {
+        THR_H_CASE(512)
+        THR_H_CASE(768)
+        THR_H_CASE(1024)
+        default:
+            return THR_ERR_UNSUPPORTED;
+    }
+#undef THR_H_CASE
+    return launch_status();
+}
+
+template <int MODE>
 static int launch_any_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
                            const float* queries, int n_queries, int ntiles, int64_t n_units,
                            int64_t unit_stride, const float* tau, int* tile_cnt, Cand* tile_list,
@@ -814,57 +888,127 @@ extern "C" size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queri
     return make_plan(n_docs, n_queries, kprime).total;
 }
 
+// K1..K4 for either scan flavour.  docs16 == nullptr: float32 scan.
+static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16* docs16,
+                          double doc_relerr, const double* dnorm, const float* inv_norm,
+                          int64_t n_docs, int dim, int64_t id_base, const float* queries,
+                          int n_queries, int k, int kprime, double* out_scores, int64_t* out_ids,
+                          int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st) {
+    float* tau = (float*)(ws + p.off_tau);
+    float* qerr = docs16 ? (float*)(ws + p.off_qerr) : nullptr;
+    int* cnt = (int*)(ws + p.off_cnt);
+    int* tcnt = (int*)(ws + p.off_tcnt);
+    Cand* cand = (Cand*)(ws + p.off_cand);
+    Cand* tlist = (Cand*)(ws + p.off_tlist);
+    float* sample = (float*)(ws + p.off_sample);
+    auto scan = [&](bool all, int64_t units, int64_t stride, float* smp, int64_t ld) -> int {
+        if (docs16)
+            return all ? launch_scan_f16<MODE_ALL>(dim, docs16, inv_norm, n_docs, queries, n_queries,
+                                                   p.ntiles, units, stride, nullptr, nullptr,
+                                                   nullptr, 0, smp, ld, st)
+                       : launch_scan_f16<MODE_FILTER>(dim, docs16, inv_norm, n_docs, queries,
+                                                      n_queries, p.ntiles, units, stride, tau, tcnt,
+                                                      tlist, p.tile_cap, nullptr, 0, st);
+        return all ? launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
+                                               p.ntiles, units, stride, nullptr, nullptr, nullptr,
+                                               0, smp, ld, st)
+                   : launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries,
+                                                  p.ntiles, units, stride, tau, tcnt, tlist,
+                                                  p.tile_cap, nullptr, 0, st);
+    };
+    hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
+    if (e != hipSuccess) return (int)e;
+    int rc;
+    if (p.sampled) {
+        if ((rc = scan(true, p.sample_groups, p.sample_stride, sample, p.sample_docs))) return rc;
+        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
+                           (int)p.sample_docs, kprime, queries, n_queries, dim, tau, qerr);
+    } else {
+        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
+                           (int64_t)0, 0, kprime, queries, n_queries, dim, tau, qerr);
+    }
+    if ((rc = launch_status())) return rc;
+    if ((rc = scan(false, p.groups, 1, nullptr, 0))) return rc;
+    hipLaunchKernelGGL(bucket_candidates, dim3(BUCKET_BLOCKS, p.ntiles), dim3(256), 0, st, tcnt,
+                       tlist, p.tile_cap, p.qtile, p.row_bits, cnt, cand);
+    if ((rc = launch_status())) return rc;
+    const double u = 5.9604644775390625e-08;
+    const double eps32 = docs16 ? ((double)dim + 16.0) * u : scan_eps(dim);
+    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), sizeof(float) * dim, st,
+                       docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
+                       p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores, out_ids,
+                       out_counts, out_flags);
+    return launch_status();
+}
+
+static int dense_args_ok(const void* docs, const void* dnorm, const void* inv_norm,
+                         const void* queries, const void* a, const void* b, const void* c,
+                         const void* d, const void* ws, int64_t n_docs, int n_queries, int k,
+                         int kprime) {
+    THR_RETURN_IF(!docs || !dnorm || !inv_norm || !queries || !a || !b || !c || !d || !ws,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || kprime < k ||
+                      kprime > THR_DENSE_MAX_K,
+                  THR_ERR_INVALID);
+    return THR_OK;
+}
+
 extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const float* inv_norm,
                               int64_t n_docs, int dim, int64_t id_base, const float* queries,
                               int n_queries, int k, int kprime, double* out_scores,
                               int64_t* out_ids, int32_t* out_counts, uint32_t* out_flags,
                               void* workspace, size_t workspace_bytes, thr_stream_t stream) {
     clear_status();
-    THR_RETURN_IF(!docs || !dnorm || !inv_norm || !queries || !out_scores || !out_ids ||
-                      !out_counts || !out_flags || !workspace,
-                  THR_ERR_INVALID);
-    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || kprime < k ||
-                      kprime > THR_DENSE_MAX_K,
-                  THR_ERR_INVALID);
+    int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
+                           out_flags, workspace, n_docs, n_queries, k, kprime);
+    if (rc) return rc;
     THR_RETURN_IF(dim <= 0 || dim % CHUNK != 0 || dim / CHUNK > 4, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS, THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, kprime);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    float* tau = (float*)(ws + p.off_tau);
-    int* cnt = (int*)(ws + p.off_cnt);
-    int* tcnt = (int*)(ws + p.off_tcnt);
-    Cand* cand = (Cand*)(ws + p.off_cand);
-    Cand* tlist = (Cand*)(ws + p.off_tlist);
-    float* sample = (float*)(ws + p.off_sample);
+    return dense_pipeline(p, docs, nullptr, 0.0, dnorm, inv_norm, n_docs, dim, id_base, queries,
+                          n_queries, k, kprime, out_scores, out_ids, out_counts, out_flags,
+                          (char*)workspace, (hipStream_t)stream);
+}
 
-    hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
+extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries,
+                                                int kprime) {
+    (void)dim;
+    if (n_docs <= 0 || n_queries <= 0) return 0;
+    return make_plan(n_docs, n_queries, kprime, KIND_F16).total;
+}
+
+extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim, uint16_t* docs16,
+                                      float* max_rel_err, thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!docs || !docs16 || !max_rel_err || n_docs <= 0 || dim <= 0, THR_ERR_INVALID);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(max_rel_err, 0, sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    int rc;
-    if (p.sampled) {
-        rc = launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
-                                       p.sample_groups, p.sample_stride, nullptr, nullptr, nullptr,
-                                       0, sample, p.sample_docs, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
-                           (int)p.sample_docs, kprime, queries, n_queries, dim, tau);
-    } else {
-        hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
-                           (int64_t)0, 0, kprime, queries, n_queries, dim, tau);
-    }
-    if ((rc = launch_status())) return rc;
-    rc = launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
-                                      p.groups, 1, tau, tcnt, tlist, p.tile_cap, nullptr, 0, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bucket_candidates, dim3(BUCKET_BLOCKS, p.ntiles), dim3(256), 0, st, tcnt, tlist,
-                       p.tile_cap, p.qtile, cnt, cand);
-    if ((rc = launch_status())) return rc;
-    const double eps = scan_eps(dim);
-    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), sizeof(float) * dim, st,
-                       docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
-                       p.qtile, k, kprime, eps, out_scores, out_ids, out_counts, out_flags);
+    hipLaunchKernelGGL(quantize_f16, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, docs,
+                       n_docs, dim, reinterpret_cast<_Float16*>(docs16),
+                       reinterpret_cast<unsigned int*>(max_rel_err));
     return launch_status();
+}
+
+extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, double doc_rel_err,
+                                  const double* dnorm, const float* inv_norm, int64_t n_docs,
+                                  int dim, int64_t id_base, const float* queries, int n_queries,
+                                  int k, int kprime, double* out_scores, int64_t* out_ids,
+                                  int32_t* out_counts, uint32_t* out_flags, void* workspace,
+                                  size_t workspace_bytes, thr_stream_t stream) {
+    clear_status();
+    int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
+                           out_flags, workspace, n_docs, n_queries, k, kprime);
+    if (rc) return rc;
+    THR_RETURN_IF(!docs16 || !(doc_rel_err >= 0.0), THR_ERR_INVALID);
+    THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
+    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
+                          inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
+                          out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream);
 }
 
 extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,
@@ -887,6 +1031,27 @@ extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, in
                                         p.groups, 1, (const float*)(ws + p.off_tau),
                                         (int*)(ws + p.off_tcnt), (Cand*)(ws + p.off_tlist),
                                         p.tile_cap, nullptr, 0, st);
+}
+
+extern "C" int thr_dense_scan_probe_f16(const uint16_t* docs16, const float* inv_norm,
+                                        int64_t n_docs, int dim, const float* queries,
+                                        int n_queries, void* workspace, size_t workspace_bytes,
+                                        thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!docs16 || !inv_norm || !queries || !workspace, THR_ERR_INVALID);
+    THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS_F16 || n_queries <= 0,
+                  THR_ERR_INVALID);
+    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
+    if (e != hipSuccess) return (int)e;
+    return launch_scan_f16<MODE_FILTER>(dim, reinterpret_cast<const _Float16*>(docs16), inv_norm,
+                                        n_docs, queries, n_queries, p.ntiles, p.groups, 1,
+                                        (const float*)(ws + p.off_tau), (int*)(ws + p.off_tcnt),
+                                        (Cand*)(ws + p.off_tlist), p.tile_cap, nullptr, 0, st);
 }
 
 extern "C" size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries) {

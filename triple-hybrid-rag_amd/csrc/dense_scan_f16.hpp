@@ -1,0 +1,270 @@
+// Shortlist scan over a float16 COPY of the corpus (opt-in: thr_dense_topk_f16).
+//
+// The float32 corpus stays the source of truth: every returned score is the float64
+// rescoring of float32 rows, and the top-k is certified with an error bound that now
+// also covers the quantisation of rows and queries (see select_rescore / DESIGN.md 4.1b):
+//     |fp16-scan score - true cosine| <= ea*(1+eq) + eq + eps32        (relative to 1)
+//   ea = max over rows of ||d16 - d|| / ||d||   (measured at index build, thr_dense_quantize_f16)
+//   eq = ||q16 - q|| / ||q||                    (measured per query in kth_select)
+//   eps32 = fp32 accumulation bound of the MFMA chain
+// What the copy buys: half the HBM bytes per corpus pass, f16 MFMA at 16x the f32 rate, and a
+// query tile of 64 (96 KiB of LDS as f16) instead of 32 -- i.e. 4x fewer bytes per query.
+//
+// Kernel structure = dense_scan_mfma2 (coalesced loads -> register ring -> per-wave LDS
+// transpose tile -> fragment reads by inline asm with hand-counted lgkmcnt), with a stage =
+// 64 dims (the same 128 B per row) and ONE v_mfma_f32_32x32x16_f16 per 16-byte fragment pair.
+#pragma once
+
+namespace thr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int H_WAVES = 8;
+constexpr int H_THREADS = H_WAVES * WAVE;
+
+template <int DIM, int MODE, bool nt_loads, int NQ>  // NQ = query sub-tiles of 32 (1 or 2)
+__global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
+    const _Float16* __restrict__ docs16, const float* __restrict__ inv_norm, int64_t n_docs,
+    const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
+    const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
+    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
+    constexpr int QT = 32 * NQ;
+    constexpr int CPR = DIM / 8;   // 16-byte chunks (8 halves) per row
+    constexpr int NG = DIM / 256;  // groups of 4 stages of 64 dims
+    constexpr int QBITS = 32 - ROW_BITS_F16;
+    static_assert(DIM % 256 == 0 && NG >= 2, "f16 scan needs dim % 256 == 0 and dim >= 512");
+    static_assert(QT <= (1 << QBITS), "query-in-tile index must fit the packed candidate word");
+    extern __shared__ float4 lds_q[];  // [QT][CPR] f16 queries | H_WAVES stage tiles | H_WAVES wbufs
+
+    const int qtile = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    f32x4* lds_v = reinterpret_cast<f32x4*>(lds_q);
+    f32x4* stage = lds_v + QT * CPR + wave * MF2_STAGE_F4;
+    Cand* wbuf = reinterpret_cast<Cand*>(lds_q + QT * CPR + H_WAVES * MF2_STAGE_F4) + wave * WBUF;
+    int wcnt = 0;
+    auto flush = [&]() {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&tile_cnt[qtile], wcnt);
+        base = __shfl(base, 0, WAVE);
+        for (int i = lane; i < wcnt; i += WAVE)
+            if (base + i < tile_cap) tile_list[(int64_t)qtile * tile_cap + base + i] = wbuf[i];
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        wcnt = 0;
+    };
+
+    // query tile: float32 -> float16 (round to nearest even), swizzled like the f32 kernels
+    for (int i = threadIdx.x; i < QT * CPR; i += H_THREADS) {
+        const int q = i / CPR, c = i % CPR;
+        const int qg = qtile * QT + q;
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+        if (qg < n_queries) {
+            const float4* src = reinterpret_cast<const float4*>(queries + (int64_t)qg * DIM + 8 * c);
+            const float4 lo = src[0], hi = src[1];
+            v[0] = (_Float16)lo.x; v[1] = (_Float16)lo.y; v[2] = (_Float16)lo.z; v[3] = (_Float16)lo.w;
+            v[4] = (_Float16)hi.x; v[5] = (_Float16)hi.y; v[6] = (_Float16)hi.z; v[7] = (_Float16)hi.w;
+        }
+        lds_v[mf_qslot(q, c, CPR)] = __builtin_bit_cast(f32x4, v);
+    }
+    __syncthreads();
+
+    float my_tau[NQ];
+#pragma unroll
+    for (int s = 0; s < NQ; ++s)
+        my_tau[s] = MODE == MODE_FILTER ? tau[qtile * QT + 32 * s + r] : 0.f;
+    const int64_t wave_id = (int64_t)blockIdx.x * H_WAVES + wave;
+    const int64_t wave_stride = (int64_t)gridDim.x * H_WAVES;
+    const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs16);
+
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    auto load_off = [&](int64_t t, int i) -> int64_t {
+        int64_t row = t * tile_stride * MF_ROWS + lrow + 8 * i;
+        row = row < n_docs ? row : n_docs - 1;
+        return row * CPR + lchunk;
+    };
+    int wslot0 = mf2_slot(lrow, lchunk), wslot1 = mf2_slot(lrow + 8, lchunk);
+    int wslot2 = mf2_slot(lrow + 16, lchunk), wslot3 = mf2_slot(lrow + 24, lchunk);
+    const uint32_t q_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_v;
+    const uint32_t st_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)stage;
+    // byte addresses: A fragment of quad j in the stage tile; query row bases of the sub-tiles
+    uint32_t ra[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = st_lds + (uint32_t)mf2_slot(r, 2 * j + h) * 16u;
+    uint32_t qrow[NQ];
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) qrow[s] = q_lds + (uint32_t)((32 * s + r) * CPR) * 16u;
+    int qlow[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) qlow[x] = (((x >> 2) * 8 + 2 * (x & 3) + h) ^ r) & 15;
+
+#define THR_PIN(x) asm volatile("" : "+v"(x))
+#define HS_LD(ptr) (nt_loads ? __builtin_nontemporal_load(&docs4[ptr]) : docs4[ptr])
+#define HS_LOAD(dst)                                       \
+    THR_PIN(p0); dst[0] = HS_LD(p0); p0 += 8;              \
+    THR_PIN(p1); dst[1] = HS_LD(p1); p1 += 8;              \
+    THR_PIN(p2); dst[2] = HS_LD(p2); p2 += 8;              \
+    THR_PIN(p3); dst[3] = HS_LD(p3); p3 += 8;
+#define HS_STORE(src)                               \
+    THR_PIN(wslot0); stage[wslot0] = src[0];        \
+    THR_PIN(wslot1); stage[wslot1] = src[1];        \
+    THR_PIN(wslot2); stage[wslot2] = src[2];        \
+    THR_PIN(wslot3); stage[wslot3] = src[3];
+    // 1 + NQ LDS reads per quad: the row fragment and one query fragment per sub-tile.
+    // qoff = chunk offset (in 16-byte units) of the stage's first chunk group (multiple of 16).
+#define HS_READ(F, quadslot, qoff, par, quad)                                                  \
+    {                                                                                          \
+        const uint32_t cb = (uint32_t)((qoff) + qlow[(par) * 4 + (quad)]) * 16u;               \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(F.a) : "v"(ra[quadslot]) : "memory");        \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(F.b[0]) : "v"(qrow[0] + cb) : "memory");     \
+        if constexpr (NQ > 1)                                                                  \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(F.b[NQ - 1]) : "v"(qrow[NQ - 1] + cb) : "memory"); \
+    }
+#define HS_WAIT2(n, F)                                                                          \
+    if constexpr (NQ > 1)                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(F.a), "+v"(F.b[0]), "+v"(F.b[NQ - 1]) : : "memory"); \
+    else                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(F.a), "+v"(F.b[0]) : : "memory");
+#define HS_MMA(F)                                                                               \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, F.a),             \
+                                                    __builtin_bit_cast(half8, F.b[0]), acc[0], 0, 0, 0); \
+    if constexpr (NQ > 1)                                                                       \
+        acc[NQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
+            __builtin_bit_cast(half8, F.a), __builtin_bit_cast(half8, F.b[NQ - 1]), acc[NQ - 1], 0, 0, 0); \
+    asm volatile("" : "+v"(acc[0]));
+    // lgkmcnt bookkeeping per stage (R = 1 + NQ reads per fragment set):
+    //   before MMA q0 / q1: younger = the other pending set           -> R
+    //   before MMA q2 / q3: younger = one set + 4 stage-tile writes   -> R + 4
+#define HS_STAGE(u, ringn, qcur, qnxt)                                       \
+    HS_WAITR(f0) HS_MMA(f0) HS_READ(f0, 2, qcur, (u) & 1, 2)                 \
+    HS_WAITR(f1) HS_MMA(f1) HS_READ(f1, 3, qcur, (u) & 1, 3)                 \
+    HS_STORE(ringn)                                                          \
+    HS_LOAD(ringn)                                                           \
+    HS_WAITR4(f0) HS_MMA(f0) HS_READ(f0, 0, qnxt, ((u) + 1) & 1, 0)          \
+    HS_WAITR4(f1) HS_MMA(f1) HS_READ(f1, 1, qnxt, ((u) + 1) & 1, 1)
+#define HS_WAITR(F)  if constexpr (NQ > 1) { HS_WAIT2(3, F) } else { HS_WAIT2(2, F) }
+#define HS_WAITR4(F) if constexpr (NQ > 1) { HS_WAIT2(7, F) } else { HS_WAIT2(6, F) }
+
+    struct Frag {
+        f32x4 a;
+        f32x4 b[NQ];
+    };
+    Frag f0, f1;
+    f0.a = f1.a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) f0.b[s] = f1.b[s] = f0.a;
+    f32x4 ring0[4], ring1[4], ring2[4], ring3[4];
+    int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    int64_t t = wave_id;
+    if (t < n_tiles) {
+        p0 = load_off(t, 0); p1 = load_off(t, 1); p2 = load_off(t, 2); p3 = load_off(t, 3);
+        HS_LOAD(ring0)
+        HS_LOAD(ring1)
+        HS_LOAD(ring2)
+        HS_LOAD(ring3)
+        HS_STORE(ring0)
+        HS_LOAD(ring0)
+        HS_READ(f0, 0, 0, 0, 0)
+        HS_READ(f1, 1, 0, 0, 1)
+    }
+    for (; t < n_tiles; t += wave_stride) {
+        const int64_t row0 = t * tile_stride * MF_ROWS;
+        int idx = r;
+        if (row0 + idx >= n_docs) idx = (int)(n_docs - 1 - row0);
+        THR_PIN(idx);
+        const float my_inv = inv_norm[row0 + idx];
+        const int64_t tn = t + wave_stride < n_tiles ? t + wave_stride : t;
+        const int64_t on0 = load_off(tn, 0), on1 = load_off(tn, 1), on2 = load_off(tn, 2),
+                      on3 = load_off(tn, 3);
+        f32x16 acc[NQ];
+#pragma unroll
+        for (int s = 0; s < NQ; ++s)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
+        // kept rolled: unrolled, every (stage, quad) LDS address becomes its own hoisted VGPR
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+            const int qb = 32 * g;                      // chunk offset of stages 4g, 4g+1
+            const int qn = g + 1 < NG ? qb + 32 : 0;    // first chunks of the next group / tile
+            HS_STAGE(0, ring1, qb, qb)
+            HS_STAGE(1, ring2, qb, qb + 16)
+            HS_STAGE(2, ring3, qb + 16, qb + 16)
+            if (g == NG - 2) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
+            HS_STAGE(3, ring0, qb + 16, qn)
+        }
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float inv = __shfl(my_inv, row, WAVE);
+                const bool ok = row0 + row < n_docs;
+                const float sc = acc[s][i] * inv;
+                if constexpr (MODE == MODE_ALL) {
+                    const int qg = qtile * QT + 32 * s + r;
+                    sample_scores[(int64_t)qg * sample_ld + t * MF_ROWS + row] =
+                        (ok && inv > 0.f) ? sc : -INFINITY;
+                } else {
+                    const bool pass = ok && inv > 0.f && sc >= my_tau[s];
+                    const uint64_t m = __ballot(pass);
+                    if (m) {
+                        const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pass)
+                            wbuf[pos] = Cand{sc, ((uint32_t)(32 * s + r) << ROW_BITS_F16) |
+                                                     (uint32_t)(row0 + row)};
+                        wcnt += __popcll(m);
+                        if (wcnt > WBUF - WAVE) flush();
+                    }
+                }
+            }
+        }
+    }
+#undef HS_WAITR4
+#undef HS_WAITR
+#undef HS_STAGE
+#undef HS_MMA
+#undef HS_WAIT2
+#undef HS_READ
+#undef HS_STORE
+#undef HS_LOAD
+#undef HS_LD
+#undef THR_PIN
+    if constexpr (MODE == MODE_FILTER) {
+        if (wcnt > 0) flush();
+    }
+}
+
+// float32 corpus -> float16 copy (round to nearest even) + the largest relative row error
+// max_d ||d16 - d|| / ||d||, accumulated as ordered float bits with atomicMax.
+__global__ __launch_bounds__(256) void quantize_f16(const float* __restrict__ docs, int64_t n_docs,
+                                                    int dim, _Float16* __restrict__ docs16,
+                                                    unsigned int* __restrict__ max_rel_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+    if (row >= n_docs) return;
+    const float* x = docs + row * dim;
+    _Float16* y = docs16 + row * dim;
+    double err = 0.0, nrm = 0.0;
+    for (int i = lane; i < dim; i += WAVE) {
+        const float v = x[i];
+        const _Float16 hv = (_Float16)v;
+        y[i] = hv;
+        const double d = (double)v - (double)(float)hv;
+        err += d * d;
+        nrm += (double)v * (double)v;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        err += __shfl_xor(err, m, WAVE);
+        nrm += __shfl_xor(nrm, m, WAVE);
+    }
+    if (lane == 0 && nrm > 0.0) {
+        // round the ratio UP to float so the stored bound is never below the true one
+        float rel = (float)sqrt(err / nrm);
+        rel = __uint_as_float(__float_as_uint(rel) + 1u);
+        atomicMax(max_rel_bits, __float_as_uint(rel));  // positive floats order like their bits
+    }
+}
+
+}  // namespace thr

@@ -354,6 +354,8 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // kept rolled: unrolled, every (stage, quad) LDS address becomes its own hoisted VGPR
+#pragma unroll 1
         for (int g = 0; g < NG; ++g) {
             const int qb = qrow + 32 * g;                           // chunks of stages 4g, 4g+1
             const int qn = g + 1 < NG ? qb + 32 : qrow;             // first chunks of the next group

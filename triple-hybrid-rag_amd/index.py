@@ -46,7 +46,8 @@ class GpuIndex:
         self.doc_base = int(doc_base)
         self.n_docs = 0
         self.dim = 0
-        self.docs = self.dnorm = self.inv_norm = None
+        self.docs = self.dnorm = self.inv_norm = self.docs16 = None
+        self.doc_rel_err = 0.0
         self.lex = None
         self.graph = None
         self.tokens = None
@@ -58,10 +59,18 @@ class GpuIndex:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
-    def set_dense(self, docs) -> "GpuIndex":
+    def set_dense(self, docs, shortlist: str = "f32") -> "GpuIndex":
+        """shortlist="f16" additionally keeps a float16 copy of the rows for the streaming
+        pass (half the bytes per pass, 64 queries per pass); scores still come from the
+        float64 rescoring of the float32 rows and the certificate covers the quantisation."""
+        if shortlist not in ("f32", "f16"):
+            raise ValueError("shortlist must be 'f32' or 'f16'")
         self.docs = self._t(docs, torch.float32)
         self.n_docs, self.dim = self.docs.shape
         self.dnorm, self.inv_norm = N.doc_norms(self.docs)
+        self.docs16, self.doc_rel_err = (None, 0.0)
+        if shortlist == "f16":
+            self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs)
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
@@ -97,10 +106,18 @@ class GpuIndex:
         fp32-error certificate cannot prove exact (massive ties / duplicates) are redone on
         the exhaustive float64 path; that check reads the flags back (one sync per batch)."""
         queries = self._t(queries, torch.float32)
-        kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
-        ws = self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
-        S, I, cnt, flg = N.dense_topk(self.docs, self.dnorm, self.inv_norm, queries, k, kp,
-                                      self.doc_base, ws)
+        if self.docs16 is not None:
+            # the quantisation-aware certificate needs a wider shortlist than the fp32 one
+            kp = min(N.THR_DENSE_MAX_K, max(k, kprime or max(2 * k + 56, 256)))
+            ws = self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim,
+                                                             queries.shape[0], kp))
+            S, I, cnt, flg = N.dense_topk_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
+                                              self.inv_norm, queries, k, kp, self.doc_base, ws)
+        else:
+            kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
+            ws = self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
+            S, I, cnt, flg = N.dense_topk(self.docs, self.dnorm, self.inv_norm, queries, k, kp,
+                                          self.doc_base, ws)
         n_rescued = 0
         if rescue:
             bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
