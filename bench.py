@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=64)
     ap.add_argument("--probe-reps", type=int, default=5)
+    ap.add_argument("--shortlist", choices=("f32", "f16"), default="f32",
+                    help="f16: opt-in float16 shortlist copy for the streaming pass (results stay "
+                         "float64-exact; see DESIGN.md 4.1b)")
     return ap.parse_args()
 
 
@@ -76,7 +79,7 @@ def main():
     docs = synth.dense_rows(lo, hi - lo, args.dim)
     queries = synth.dense_queries(args.queries, args.dim, args.docs)
     gen_s = time.time() - t0
-    index = T.GpuIndex(doc_base=lo).set_dense(docs)
+    index = T.GpuIndex(doc_base=lo).set_dense(docs, shortlist=args.shortlist)
     sharded = ShardedIndex(index)
     qd = torch.from_numpy(queries).cuda()
     torch.cuda.synchronize()
@@ -107,28 +110,36 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around the scan alone ----
     n_local = hi - lo
-    ws = index._workspace(T._native.dense_workspace_bytes(n_local, args.dim, args.queries, 128))
+    f16 = args.shortlist == "f16"
+    if f16:
+        ws = index._workspace(T._native.dense_f16_workspace_bytes(n_local, args.dim, args.queries, 256))
+        probe = lambda: T._native.dense_scan_probe_f16(index.docs16, index.inv_norm, qd, ws)
+        qt = 64 if args.dim <= 768 else 32
+        elem = 2
+    else:
+        ws = index._workspace(T._native.dense_workspace_bytes(n_local, args.dim, args.queries, 128))
+        probe = lambda: T._native.dense_scan_probe(index.docs, index.inv_norm, qd, ws)
+        qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
+        elem = 4
     stream = torch.cuda.current_stream()
-    T._native.dense_scan_probe(index.docs, index.inv_norm, qd, ws)  # warm
+    probe()  # warm
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(stream)
     for _ in range(args.probe_reps):
-        T._native.dense_scan_probe(index.docs, index.inv_norm, qd, ws)
+        probe()
     ev1.record(stream)
     torch.cuda.synchronize()
     scan_ms = ev0.elapsed_time(ev1) / args.probe_reps
-    qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
     tiles = (args.queries + qt - 1) // qt
-    alg_bytes = tiles * n_local * args.dim * 4
+    alg_bytes = tiles * n_local * args.dim * elem
     achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
-    impl = "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2"
     # HBM bytes from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per tile pass;
     # only valid for the shape it was measured on
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
             pm = json.load(f)
-        if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt == 32:
+        if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt == 32 and not f16:
             traffic = round(pm["hbm_bytes_per_tile_pass"] * tiles)
     except (OSError, KeyError, ValueError):
         pass
@@ -165,12 +176,13 @@ def main():
             "metric": "queries/sec (fused top-10)", "value": round(qps, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 scan + f64 rescoring",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": ("f16 shortlist scan" if f16 else "f32 scan") + " + f64 rescoring of f32 rows",
             "data": "synthetic",
             "config": {"workload": f"{args.docs}-doc / {args.dim}-d dense-only brute-force cosine "
                                    f"top-{args.top_k} (BASELINE.json configs[1])",
                        "docs": args.docs, "dim": args.dim, "queries_per_step": args.queries,
-                       "semantic_top_k": 100, "fused_top_k": args.top_k,
+                       "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": args.shortlist,
                        "parallelism": f"doc-shard x{world}" if world > 1 else "single GPU",
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -674,13 +674,20 @@ static int mfma_version() {
 }
 
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
-constexpr int F16_NQ = 2;  // 64 queries per tile pass on the float16 copy
+// query sub-tiles of 32 per pass on the float16 copy: 2 (64 queries, 96 KiB of LDS at dim 768)
+// when the tile fits next to the transpose tiles, else 1
+static size_t f16_lds_bytes(int dim, int nq) {
+    return sizeof(_Float16) * 32 * nq * (size_t)dim +
+           (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES;
+}
+static int f16_nq(int dim) { return f16_lds_bytes(dim, 2) <= 160 * 1024 ? 2 : 1; }
 
-static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32) {
+static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
+                           int dim = 0) {
     DensePlan p;
     p.kind = kind;
     p.row_bits = kind == KIND_F16 ? ROW_BITS_F16 : ROW_BITS;
-    p.qtile = kind == KIND_F16 ? 32 * F16_NQ : (use_mfma() ? MF_QT : query_tile());
+    p.qtile = kind == KIND_F16 ? 32 * f16_nq(dim) : (use_mfma() ? MF_QT : query_tile());
     p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
@@ -829,8 +836,8 @@ static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_nor
                            const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
                            int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    const size_t lds = sizeof(_Float16) * 32 * F16_NQ * (size_t)dim +
-                       (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES;
+    const int nq = f16_nq(dim);
+    const size_t lds = f16_lds_bytes(dim, nq);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     int64_t blocks = (n_row_tiles + H_WAVES - 1) / H_WAVES;
     if (blocks > num_cus()) blocks = num_cus();
@@ -838,7 +845,7 @@ static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_nor
     dim3 grid((unsigned)blocks, (unsigned)ntiles);
 #define THR_H_CASE(DIM)                                                                           \
     case DIM: {                                                                                   \
-        auto kern = dense_scan_f16<DIM, MODE, true, F16_NQ>;                                      \
+        auto kern = nq == 2 ? dense_scan_f16<DIM, MODE, true, 2> : dense_scan_f16<DIM, MODE, true, 1>; \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \
@@ -973,9 +980,8 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
 
 extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries,
                                                 int kprime) {
-    (void)dim;
     if (n_docs <= 0 || n_queries <= 0) return 0;
-    return make_plan(n_docs, n_queries, kprime, KIND_F16).total;
+    return make_plan(n_docs, n_queries, kprime, KIND_F16, dim).total;
 }
 
 extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim, uint16_t* docs16,
@@ -1004,7 +1010,7 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
     THR_RETURN_IF(!docs16 || !(doc_rel_err >= 0.0), THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
-    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16);
+    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
                           inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
@@ -1042,7 +1048,7 @@ extern "C" int thr_dense_scan_probe_f16(const uint16_t* docs16, const float* inv
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS_F16 || n_queries <= 0,
                   THR_ERR_INVALID);
-    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16);
+    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
