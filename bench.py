@@ -143,6 +143,8 @@ def main():
             traffic = round(pm["hbm_bytes_per_tile_pass"] * tiles)
     except (OSError, KeyError, ValueError):
         pass
+    impl = "dense_scan_f16" if f16 else (
+        "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2")
     roofline = {"bound": "hbm", "kernel": f"{impl}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
