@@ -694,8 +694,11 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     const int64_t groups = (n_docs + p.unit - 1) / p.unit;
     // sample only when the corpus is larger than what the candidate list can hold anyway
     p.sampled = n_docs > CAND_CAP / 2;
-    int64_t target = n_docs / 32;
-    if (target > SAMPLE_TARGET) target = SAMPLE_TARGET;
+    // sample size: the expected number of rows passing tau is (n / sample) * k' per query;
+    // aim at 4096 (a quarter of CAND_CAP, half of a tile list's share)
+    int64_t target = n_docs * (int64_t)kprime / 4096;
+    const int64_t target_max = (int64_t)SAMPLE_TARGET * kprime / 128;
+    if (target > target_max) target = target_max;
     if (target < 4 * (int64_t)kprime) target = 4 * (int64_t)kprime;
     int64_t sg = (target + p.unit - 1) / p.unit;
     if (sg > groups) sg = groups;
