@@ -492,14 +492,46 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     __syncthreads();
     const int ns = n_sel;
 
-    // float64 rescoring, one thread per shortlisted row; the last thread takes ||q||
-    if (threadIdx.x == SEL_THREADS - 1) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
-    double dot = 0.0;
-    int64_t row = -1;
-    if (threadIdx.x < ns) {
-        row = s_id[threadIdx.x];
-        dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
+    // float64 rescoring, one thread per shortlisted row (the contract is a SEQUENTIAL float64
+    // sum, so a row cannot be split over lanes).  Rows are staged through LDS 32 dims at a
+    // time with coalesced loads (8 lanes per 128-B line): a thread walking its own 3 KiB row
+    // straight from HBM would wait one memory round trip per 16 bytes.
+    constexpr int RS_STRIDE = 9;  // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
+    float4* rstage = reinterpret_cast<float4*>(lds_qv + dim);
+    const float4* docs4 = reinterpret_cast<const float4*>(docs);
+    double dot = 0.0, qq = 0.0;
+    const int64_t row = threadIdx.x < ns ? s_id[threadIdx.x] : -1;
+    for (int d0 = 0; d0 < dim; d0 += 32) {
+        float4 tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = u * SEL_THREADS + threadIdx.x;
+            const int rs = it >> 3, ch = it & 7;
+            tmp[u] = rs < ns ? docs4[(s_id[rs] * dim + d0) / 4 + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int it = u * SEL_THREADS + threadIdx.x;
+            rstage[(it >> 3) * RS_STRIDE + (it & 7)] = tmp[u];
+        }
+        __syncthreads();
+        if (threadIdx.x < ns) {
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const float4 x = rstage[threadIdx.x * RS_STRIDE + ch];
+                const float* qv = lds_qv + d0 + 4 * ch;
+                dot = __dadd_rn(dot, __dmul_rn((double)x.x, (double)qv[0]));
+                dot = __dadd_rn(dot, __dmul_rn((double)x.y, (double)qv[1]));
+                dot = __dadd_rn(dot, __dmul_rn((double)x.z, (double)qv[2]));
+                dot = __dadd_rn(dot, __dmul_rn((double)x.w, (double)qv[3]));
+            }
+        }
+        if (threadIdx.x == SEL_THREADS - 1)  // ||q||^2, same sequential order as seq_dot_f64
+            for (int i = d0; i < d0 + 32; ++i)
+                qq = __dadd_rn(qq, __dmul_rn((double)lds_qv[i], (double)lds_qv[i]));
+        __syncthreads();
     }
+    if (threadIdx.x == SEL_THREADS - 1) s_qn = __dsqrt_rn(qq);
     __syncthreads();
     if (threadIdx.x < ns) {
         const double qn = s_qn, dn = dnorm[row];
@@ -944,7 +976,8 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     if ((rc = launch_status())) return rc;
     const double u = 5.9604644775390625e-08;
     const double eps32 = docs16 ? ((double)dim + 16.0) * u : scan_eps(dim);
-    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), sizeof(float) * dim, st,
+    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS),
+                       sizeof(float) * dim + sizeof(float4) * SEL_THREADS * 9, st,
                        docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
                        p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores, out_ids,
                        out_counts, out_flags);
