@@ -314,37 +314,16 @@ __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__
 // keyfn(i) -> uint32 order-preserving key.  Returns the key; *n_greater gets the
 // number of keys strictly greater.  hist = 256 ints of LDS, bc = 4 ints of LDS.
 // ---------------------------------------------------------------------------
-// Histogram increment for one radix digit.  The leading digits of score keys are shared by
-// almost every element (same sign/exponent), so plain LDS atomics would serialise on a handful
-// of bins; there the wave first groups equal digits with ballots and issues one atomic per
-// distinct value.  Later digits are well spread and use plain atomics.
-__device__ __forceinline__ void hist_add(int* hist, int digit, bool valid, bool aggregate) {
-    if (!aggregate) {
-        if (valid) atomicAdd(&hist[digit], 1);
-        return;
-    }
-    uint64_t todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((unsigned long long)todo) - 1;
-        const int d = __shfl(digit, leader, WAVE);
-        const uint64_t same = __ballot(valid && digit == d) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], __popcll(same));
-        todo &= ~same;
-    }
-}
-
 template <typename KeyFn>
 __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, int* bc, int* n_greater) {
     uint32_t prefix = 0, mask = 0;
     int remaining = kk, greater = 0;
-    const int n_round = (n + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves in the loop
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n_round; i += blockDim.x) {
-            const bool in = i < n;
-            const uint32_t key = in ? keyfn(i) : 0u;
-            hist_add(hist, (key >> shift) & 255, in && (key & mask) == prefix, shift >= 16);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            uint32_t key = keyfn(i);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
