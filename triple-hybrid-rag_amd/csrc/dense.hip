@@ -321,9 +321,20 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            uint32_t key = keyfn(i);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        // 8 keys per thread per trip, loads issued together: one dependent load per
+        // trip would make every pass a chain of memory round trips
+        for (int base = threadIdx.x; base < n; base += 8 * blockDim.x) {
+            uint32_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * blockDim.x;
+                key[u] = i < n ? keyfn(i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * blockDim.x;
+                if (i < n && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255], 1);
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
