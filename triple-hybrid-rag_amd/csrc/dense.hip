@@ -312,20 +312,15 @@ __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__
 // ---------------------------------------------------------------------------
 // 8-bit-digit radix select of the kk-th largest key among n (block-wide).
 // keyfn(i) -> uint32 order-preserving key.  Returns the key; *n_greater gets the
-// number of keys strictly greater.  hist = RS_COPIES*256 ints of LDS, bc = 4 ints of LDS.
-// The leading digits of score keys are shared by almost every element (same sign and
-// exponent), and same-address LDS atomics serialise: 16 lane-interleaved histogram copies
-// cut that 16-fold; they are summed before the bin scan.
+// number of keys strictly greater.  hist = 256 ints of LDS, bc = 4 ints of LDS.
 // ---------------------------------------------------------------------------
-constexpr int RS_COPIES = 16;
 template <typename KeyFn>
 __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, int* bc, int* n_greater) {
     uint32_t prefix = 0, mask = 0;
     int remaining = kk, greater = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < RS_COPIES * 256; i += blockDim.x) hist[i] = 0;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        int* my_hist = hist + (threadIdx.x & (RS_COPIES - 1)) * 256;
         // 8 keys per thread per trip, loads issued together: one dependent load per
         // trip would make every pass a chain of memory round trips
         for (int base = threadIdx.x; base < n; base += 8 * blockDim.x) {
@@ -338,15 +333,8 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * blockDim.x;
-                if (i < n && (key[u] & mask) == prefix) atomicAdd(&my_hist[(key[u] >> shift) & 255], 1);
+                if (i < n && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255], 1);
             }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-            int sum = 0;
-#pragma unroll
-            for (int c = 0; c < RS_COPIES; ++c) sum += hist[c * 256 + i];
-            hist[i] = sum;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -393,7 +381,7 @@ __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ samp
                                                   const float* __restrict__ queries, int n_queries,
                                                   int dim, float* __restrict__ tau,
                                                   float* __restrict__ qerr) {
-    __shared__ int hist[RS_COPIES * 256];
+    __shared__ int hist[256];
     __shared__ int bc[4];
     __shared__ int flag;
     __shared__ double red[2][256];
@@ -463,7 +451,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores, int64_t* __restrict__ out_ids,
     int32_t* __restrict__ out_counts, uint32_t* __restrict__ out_flags) {
     extern __shared__ float lds_qv[];  // [dim] query
-    __shared__ int hist[RS_COPIES * 256];
+    __shared__ int hist[256];
     __shared__ int bc[4];
     __shared__ double s_s[THR_DENSE_MAX_K];
     __shared__ int64_t s_id[THR_DENSE_MAX_K];
