@@ -476,29 +476,75 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     if (threadIdx.x == 0) n_sel = 0;
     __syncthreads();
 
-    // shortlist: the kprime best float32 scores (ties at the floor: first come)
+    // ||q|| upper bound (parallel float64 sum, inflated) -- only used to size the band below
+    __shared__ double red[SEL_THREADS];
+    {
+        double part = 0.0;
+        for (int i = threadIdx.x; i < dim; i += SEL_THREADS) part += (double)lds_qv[i] * (double)lds_qv[i];
+        red[threadIdx.x] = part;
+        __syncthreads();
+        for (int o = SEL_THREADS / 2; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+    }
+    const double qn_hi = sqrt(red[0]) * (1.0 + 1e-6);
+
+    // Shortlist = the BAND of candidates that can still reach the top-k.  With a_k the k-th
+    // largest scan score, k rows have true cosine >= a_k/||q|| - eps, so a row whose scan score
+    // is below a_k - 2*eps*||q|| cannot beat them; only the band [a_k - 2.5*eps*||q||, inf) is
+    // rescored (typically k plus a handful of rows instead of k').  Fallbacks: everything when
+    // the list is short; the kprime best when the band does not fit the block.
     float floor32 = tau[q];
-    if (n > kprime) {
+    bool band_done = false;
+    if (n > k && n > 0) {
         int greater;
-        uint32_t tkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, kprime, hist,
-                                           bc, &greater);
-        floor32 = fkey_inv(tkey);
-        for (int i = threadIdx.x; i < n; i += SEL_THREADS)
-            if (fkey(c[i].score) > tkey) {
-                int p = atomicAdd(&n_sel, 1);
-                s_id[p] = c[i].doc;
-            }
+        uint32_t kkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, k, hist, bc,
+                                           &greater);
+        const float band = (float)((double)fkey_inv(kkey) - 2.5 * eps * qn_hi);
+        const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
+        __shared__ int n_band;
+        if (threadIdx.x == 0) n_band = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += SEL_THREADS)
-            if (fkey(c[i].score) == tkey) {
-                int p = atomicAdd(&n_sel, 1);
-                if (p < kprime) s_id[p] = c[i].doc;
-            }
+        int mine = 0;
+        for (int i = threadIdx.x; i < n; i += SEL_THREADS) mine += c[i].score >= band_lo ? 1 : 0;
+        if (mine) atomicAdd(&n_band, mine);
         __syncthreads();
-        if (threadIdx.x == 0 && n_sel > kprime) n_sel = kprime;
-    } else {
-        for (int i = threadIdx.x; i < n; i += SEL_THREADS) s_id[i] = c[i].doc;
-        if (threadIdx.x == 0) n_sel = n;
+        if (n_band <= THR_DENSE_MAX_K && band_lo > -INFINITY) {
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+                if (c[i].score >= band_lo) {
+                    int p = atomicAdd(&n_sel, 1);
+                    s_id[p] = c[i].doc;
+                }
+            // rows outside the band: uncollected ones are below tau, collected ones below band_lo
+            floor32 = fmaxf(floor32, band_lo);
+            band_done = true;
+        }
+        __syncthreads();
+    }
+    if (!band_done) {
+        if (n > kprime) {
+            int greater;
+            uint32_t tkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, kprime,
+                                               hist, bc, &greater);
+            floor32 = fkey_inv(tkey);
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+                if (fkey(c[i].score) > tkey) {
+                    int p = atomicAdd(&n_sel, 1);
+                    s_id[p] = c[i].doc;
+                }
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
+                if (fkey(c[i].score) == tkey) {
+                    int p = atomicAdd(&n_sel, 1);
+                    if (p < kprime) s_id[p] = c[i].doc;
+                }
+            __syncthreads();
+            if (threadIdx.x == 0 && n_sel > kprime) n_sel = kprime;
+        } else {
+            for (int i = threadIdx.x; i < n; i += SEL_THREADS) s_id[i] = c[i].doc;
+            if (threadIdx.x == 0) n_sel = n;
+        }
     }
     __syncthreads();
     const int ns = n_sel;
