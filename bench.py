@@ -111,14 +111,11 @@ def main():
     # ---- roofline of the dominant kernel: HIP events around the scan alone ----
     n_local = hi - lo
     f16 = args.shortlist == "f16"
+    probe = lambda: index.scan_probe(qd)  # same workspace (and tau) as the timed searches
     if f16:
-        ws = index._workspace(T._native.dense_f16_workspace_bytes(n_local, args.dim, args.queries, 256))
-        probe = lambda: T._native.dense_scan_probe_f16(index.docs16, index.inv_norm, qd, ws)
         qt = 64 if args.dim <= 768 else 32
         elem = 2
     else:
-        ws = index._workspace(T._native.dense_workspace_bytes(n_local, args.dim, args.queries, 128))
-        probe = lambda: T._native.dense_scan_probe(index.docs, index.inv_norm, qd, ws)
         qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
         elem = 4
     stream = torch.cuda.current_stream()

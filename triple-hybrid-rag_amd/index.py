@@ -129,6 +129,17 @@ class GpuIndex:
                 S[bad], I[bad], cnt[bad] = S2, I2, c2
         return S, I, cnt, n_rescued
 
+    def scan_probe(self, queries: torch.Tensor) -> None:
+        """Launch ONLY the streaming scan kernel of the last dense_search (same workspace, so the
+        thresholds tau are the ones that search computed): the timing/roofline probe."""
+        if self._ws is None:
+            raise N.NativeError("scan_probe needs a preceding dense_search on this index")
+        queries = self._t(queries, torch.float32)
+        if self.docs16 is not None:
+            N.dense_scan_probe_f16(self.docs16, self.inv_norm, queries, self._ws)
+        else:
+            N.dense_scan_probe(self.docs, self.inv_norm, queries, self._ws)
+
     def bm25_search(self, query_terms: torch.Tensor, k: int):
         L = self.lex
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
