@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=64)
     ap.add_argument("--probe-reps", type=int, default=5)
+    ap.add_argument("--no-f16-extra", action="store_true",
+                    help="skip the additional float16-shortlist measurement reported next to the "
+                         "default float32-scan one")
     ap.add_argument("--shortlist", choices=("f32", "f16"), default="f32",
                     help="f16: opt-in float16 shortlist copy for the streaming pass (results stay "
                          "float64-exact; see DESIGN.md 4.1b)")
@@ -92,61 +95,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    t0 = time.perf_counter()
-    rescued = 0
-    for _ in range(args.steps):
-        res = step()
-        rescued += res.rescued
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure():
+        """W warm-up steps, then K timed steps between barriers; max over ranks."""
+        res, rescued = None, 0
+        for _ in range(args.warmup):
+            res = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+            rescued += res.rescued
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return res, rescued, elapsed
+
+    def probe_scan(f16):
+        """Average launch time of the streaming scan kernel alone (HIP events on its stream)."""
+        stream = torch.cuda.current_stream()
+        index.scan_probe(qd)  # warm; same workspace (and tau) as the timed searches
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(args.probe_reps):
+            index.scan_probe(qd)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / args.probe_reps
+        if f16:
+            qt, elem, name = (64 if args.dim <= 768 else 32), 2, "dense_scan_f16"
+        else:
+            qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
+            elem = 4
+            name = "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2"
+        tiles = (args.queries + qt - 1) // qt
+        alg = tiles * (hi - lo) * args.dim * elem
+        ach = alg / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": f"{name}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+                "tile_passes_per_launch": tiles, "algorithmic_bytes_per_launch": alg}, qt, tiles
+
+    res, rescued, elapsed = measure()
     qps = args.steps * args.queries / elapsed
 
     # ---- roofline of the dominant kernel: HIP events around the scan alone ----
     n_local = hi - lo
     f16 = args.shortlist == "f16"
-    probe = lambda: index.scan_probe(qd)  # same workspace (and tau) as the timed searches
-    if f16:
-        qt = 64 if args.dim <= 768 else 32
-        elem = 2
-    else:
-        qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
-        elem = 4
-    stream = torch.cuda.current_stream()
-    probe()  # warm
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(stream)
-    for _ in range(args.probe_reps):
-        probe()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    scan_ms = ev0.elapsed_time(ev1) / args.probe_reps
-    tiles = (args.queries + qt - 1) // qt
-    alg_bytes = tiles * n_local * args.dim * elem
-    achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
+    roofline, qt, tiles = probe_scan(f16)
     # HBM bytes from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per tile pass;
     # only valid for the shape it was measured on
-    traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
             pm = json.load(f)
         if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt == 32 and not f16:
-            traffic = round(pm["hbm_bytes_per_tile_pass"] * tiles)
+            roofline["traffic"] = round(pm["hbm_bytes_per_tile_pass"] * tiles)
     except (OSError, KeyError, ValueError):
         pass
-    impl = "dense_scan_f16" if f16 else (
-        "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2")
-    roofline = {"bound": "hbm", "kernel": f"{impl}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "launch_ms": round(scan_ms, 4), "tile_passes_per_launch": tiles,
-                "algorithmic_bytes_per_launch": alg_bytes}
+
+    # ---- the opt-in float16 shortlist copy, measured in the same run for comparison ----
+    extra = None
+    if not f16 and not args.no_f16_extra and args.dim in (512, 768, 1024):
+        ids_f32 = res.ids.clone()
+        index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(index.docs)
+        res16, rescued16, elapsed16 = measure()
+        roof16, _, _ = probe_scan(True)
+        extra = {"value": round(args.steps * args.queries / elapsed16, 1), "unit": "queries/s",
+                 "ms_per_step": round(1e3 * elapsed16 / args.steps, 3),
+                 "rescued_queries": rescued16, "roofline": roof16,
+                 "fused_top10_identical_to_f32_scan": bool(torch.equal(res16.ids, ids_f32)),
+                 "note": "float16 copy of the rows for the streaming pass only; scores are the "
+                         "float64 rescoring of float32 rows, certificate covers quantisation"}
+        index.docs16, index.doc_rel_err = None, 0.0
 
     # ---- exactness of what was timed + CPU baseline (rank 0, N = 1) ----
     cpu = None
@@ -186,6 +208,8 @@ def main():
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if extra:
+            out["f16_shortlist"] = extra
         if check:
             out["parity_check"] = check
         print(json.dumps(out), flush=True)
