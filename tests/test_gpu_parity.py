@@ -435,3 +435,68 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d):
     S, I, cnt, nres = idx.dense_search(dev(q), 100)
     Se, Ie, cnte = CO.dense_topk_exact(x, q, 100, doc_id_base=123)
     assert_topk_equal(S, I, cnt, Se, Ie, cnte, "dense-f16")
+
+
+def _sharded_worker(rank, world, port, n, d, out_dir):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import triple_hybrid_rag_amd as T
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import ShardedIndex, shard_range
+    torch.cuda.set_device(0)
+    lo, hi = shard_range(n, rank, world)
+    v = synth.vocab_size(n)
+    doc, term, tf = synth.lexical_rows(lo, hi - lo, n)
+    csr = synth.build_lexical_csr(doc, term, tf, hi - lo, v)
+    # global statistics: every rank needs the df / doc-length sums of the whole corpus
+    df = torch.from_numpy(csr.df_local.copy())
+    sdl = torch.tensor([csr.sum_dl_local], dtype=torch.float64)
+    dist.all_reduce(df)
+    dist.all_reduce(sdl)
+    idf = O.bm25_idf(n, df.numpy())
+    g = synth.build_graph(n, lo, hi)
+    idx = (T.GpuIndex(doc_base=lo).set_dense(synth.dense_rows(lo, hi - lo, d))
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, float(sdl.item()) / n)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf))
+    q = synth.dense_queries(24, d, n)
+    dfq = df.numpy().copy()
+    qt = synth.lexical_queries(24, dfq, 4)
+    seeds = synth.graph_queries(24, n, 3)
+    res = ShardedIndex(idx).retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ids.npy"), res.ids.cpu().numpy())
+        np.save(os.path.join(out_dir, "sc.npy"), res.scores.cpu().numpy())
+        np.save(os.path.join(out_dir, "df.npy"), df.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
+    """Config-4 shape, 2 document shards (two processes sharing this GPU, gloo rendezvous standing
+    in for RCCL): per-shard kernels + all-gather + thr_merge_topk + RRF == unsharded oracle."""
+    import os
+    import torch.multiprocessing as mp
+    from triple_hybrid_rag_amd import synth
+    n, d, world = 30000, 768, 2
+    port = 29700 + os.getpid() % 1500
+    mp.get_context("spawn")
+    mp.spawn(_sharded_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
+    ids, sc = np.load(tmp_path / "ids.npy"), np.load(tmp_path / "sc.npy")
+    df = np.load(tmp_path / "df.npy")
+    x = synth.dense_rows(0, n, d)
+    q = synth.dense_queries(24, d, n)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    assert np.array_equal(df, csr.df_local)
+    qt = synth.lexical_queries(24, csr.df_local, 4)
+    g = synth.build_graph(n)
+    seeds = synth.graph_queries(24, n, 3)
+    _, Id, _ = CO.dense_topk_exact(x, q, 100)
+    _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
+    _, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf, seeds, 2, n, 50)
+    for i in range(24):
+        ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 10)
+        assert list(ids[i]) == ei and list(sc[i]) == es

@@ -30,18 +30,21 @@ def shard_range(n_docs: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather each rank's [nq, k] (scores, ids) -> [world, nq, k] on every rank.
-    Backend-agnostic (RCCL on GPUs; gloo in the CPU tests)."""
+    """All-gather each rank's [nq, k] (scores f64, ids i64) -> [world, nq, k] on every rank.
+    ONE collective per channel: the float64 scores travel as their int64 bit patterns next to
+    the ids in a single [2, nq, k] int64 tile (the exchange is latency-bound, not
+    bandwidth-bound).  Backend-agnostic (RCCL on GPUs; gloo in the CPU tests)."""
     world = dist.get_world_size(group)
-    S = torch.empty((world,) + tuple(scores.shape), dtype=scores.dtype, device=scores.device)
-    I = torch.empty((world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+    tile = torch.stack([scores.contiguous().view(torch.int64), ids.contiguous()])  # [2, nq, k]
+    out = torch.empty((world,) + tuple(tile.shape), dtype=torch.int64, device=tile.device)
     if dist.get_backend(group) == "gloo":
-        dist.all_gather(list(S.unbind(0)), scores.contiguous(), group=group)
-        dist.all_gather(list(I.unbind(0)), ids.contiguous(), group=group)
+        # CPU rendezvous (tests / rehearsals): stage through host memory if the tiles are on a GPU
+        host = [torch.empty(tile.shape, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(host, tile.cpu(), group=group)
+        out = torch.stack(host).to(tile.device)
     else:
-        dist.all_gather_into_tensor(S, scores.contiguous(), group=group)
-        dist.all_gather_into_tensor(I, ids.contiguous(), group=group)
-    return S, I
+        dist.all_gather_into_tensor(out, tile, group=group)
+    return out[:, 0].contiguous().view(torch.float64), out[:, 1].contiguous()
 
 
 class ShardedIndex:
