@@ -145,15 +145,20 @@ def main():
     n_local = hi - lo
     f16 = args.shortlist == "f16"
     roofline, qt, tiles = probe_scan(f16)
-    # HBM bytes from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per tile pass;
-    # only valid for the shape it was measured on
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
-            pm = json.load(f)
-        if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt == 32 and not f16:
-            roofline["traffic"] = round(pm["hbm_bytes_per_tile_pass"] * tiles)
-    except (OSError, KeyError, ValueError):
-        pass
+
+    def pmc_traffic(kind, qt_expected, ntiles):
+        """HBM bytes per launch from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per
+        tile pass; only valid for the shape it was measured on."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
+                pm = json.load(f)
+            if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt_expected:
+                return round(pm[kind]["hbm_bytes_per_tile_pass"] * ntiles)
+        except (OSError, KeyError, ValueError):
+            pass
+        return None
+
+    roofline["traffic"] = pmc_traffic("f16" if f16 else "f32", qt == (64 if f16 else 32), tiles)
 
     # ---- the opt-in float16 shortlist copy, measured in the same run for comparison ----
     extra = None
@@ -161,7 +166,8 @@ def main():
         ids_f32 = res.ids.clone()
         index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(index.docs)
         res16, rescued16, elapsed16 = measure()
-        roof16, _, _ = probe_scan(True)
+        roof16, qt16, tiles16 = probe_scan(True)
+        roof16["traffic"] = pmc_traffic("f16", qt16 == 64, tiles16)
         extra = {"value": round(args.steps * args.queries / elapsed16, 1), "unit": "queries/s",
                  "ms_per_step": round(1e3 * elapsed16 / args.steps, 3),
                  "rescued_queries": rescued16, "roofline": roof16,
