@@ -500,3 +500,35 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
     for i in range(24):
         ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 10)
         assert list(ids[i]) == ei and list(sc[i]) == es
+
+
+@pytest.mark.parametrize("shortlist", ["f32", "f16"])
+def test_dense_edge_shapes_and_near_ties(T, shortlist):
+    rng = np.random.default_rng(31)
+    # tiny corpora, k > n, single query, k = 1
+    for n, d, nq, k in ((1, 768, 1, 5), (33, 768, 2, 100), (300, 512, 1, 1), (9000, 768, 3, 7)):
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        idx = T.GpuIndex(doc_base=5).set_dense(x, shortlist=shortlist)
+        S, I, cnt, _ = idx.dense_search(dev(q), k)
+        Se, Ie, cnte = CO.dense_topk_exact(x, q, k, doc_id_base=5)
+        assert_topk_equal(S, I, cnt, Se, Ie, cnte, f"edge n={n}")
+    # a cloud of near-duplicates around the query: hundreds of rows inside the error band
+    n, d = 40000, 768
+    x, _ = rand_docs(n, d, 41)
+    base = x[7].copy()
+    x[1000:1600] = base + 1e-6 * rng.standard_normal((600, d)).astype(np.float32)
+    x[2000:2050] = base + 1e-3 * rng.standard_normal((50, d)).astype(np.float32)
+    q = np.stack([base, base + 0.01 * x[8], x[9]]).astype(np.float32)
+    idx = T.GpuIndex().set_dense(x, shortlist=shortlist)
+    S, I, cnt, nres = idx.dense_search(dev(q), 100)
+    assert nres >= 1                      # the cloud cannot be certified from a 256-row shortlist
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 100)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "near-ties")
+    # unnormalised rows and queries (cosine must divide by both norms)
+    x2 = (x[:20000] * rng.uniform(0.1, 30.0, (20000, 1))).astype(np.float32)
+    q2 = (q * 13.0).astype(np.float32)
+    idx = T.GpuIndex().set_dense(x2, shortlist=shortlist)
+    S, I, cnt, _ = idx.dense_search(dev(q2), 50)
+    Se, Ie, cnte = CO.dense_topk_exact(x2, q2, 50)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "unnormalised")

@@ -44,6 +44,4 @@ def test_no_cpu_fallback_in_the_product_package():
         for f in files:
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("oracle's", "").replace("the oracle", "") \
-                    .replace("oracle contract", "").replace("oracle/", "") or True
                 assert "import oracle" not in src and "from oracle" not in src, f
