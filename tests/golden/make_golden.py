@@ -424,6 +424,26 @@ def gen_standalone(rng):
     return out
 
 
+def gen_planner(rng):
+    """Rule-based planner of the standalone package (no GPT call)."""
+    from triple_hybrid_rag.core.query_planner import QueryPlanner
+    qp = QueryPlanner.__new__(QueryPlanner)
+    qp.config = RAGConfig()
+    queries = ["What is the refund policy?", "how do I reset my password", "Compare plan A and plan B",
+               "Who works for Acme Corp?", "the of and", "Refund refund REFUND policy.",
+               "difference between (premium) and [basic] tiers!", "define SLA", "",
+               "which organization is related to Bob's company", "a b cd efg"]
+    out = []
+    for q in queries:
+        plan = qp._simple_plan(q)
+        out.append({"query": q, "keywords": plan.keywords, "requires_graph": plan.requires_graph,
+                    "intent": plan.intent, "weights": plan.weights,
+                    "semantic_query_text": plan.semantic_query_text,
+                    "top_ks": [plan.lexical_top_k, plan.semantic_top_k, plan.graph_top_k],
+                    "cypher_query": plan.cypher_query})
+    return out
+
+
 def main():
     rng = random.Random(20260130)
     dump("embed_postproc.json", gen_embed(rng))
@@ -433,6 +453,7 @@ def main():
     dump("retrieve_traces.json", gen_retrieve(rng))
     dump("legacy_rerank.json", gen_legacy(rng))
     dump("standalone_fusion.json", gen_standalone(rng))
+    dump("simple_planner.json", gen_planner(rng))
     dump("defaults.json", {
         "settings": {k: getattr(SETTINGS, k) for k in (
             "rag2_enabled", "rag2_graph_enabled", "rag2_rerank_enabled", "rag2_denoise_enabled",

@@ -532,3 +532,41 @@ def test_dense_edge_shapes_and_near_ties(T, shortlist):
     S, I, cnt, _ = idx.dense_search(dev(q2), 50)
     Se, Ie, cnte = CO.dense_topk_exact(x2, q2, 50)
     assert_topk_equal(S, I, cnt, Se, Ie, cnte, "unnormalised")
+
+
+def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
+    """8f.3 / 8f.4: the single-call hybrid RPC and the RAG 1.0 searcher run on the same kernels."""
+    import asyncio
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    from triple_hybrid_rag_amd.retrieval.hybrid_search import HybridSearcher, SearchConfig
+    n, d = 20000, 768
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    idx = T.GpuIndex().set_dense(x).set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+    client = GpuIndexClient(idx, CorpusStore.synthetic(n, vocab_size=v), org_id="org")
+    q = synth.dense_queries(3, d, n)
+    for qi in range(3):
+        terms = [100 + qi, 2000 + qi, 77]
+        text = " ".join(f"t{t}" for t in terms)
+        rows = client.rpc("rag2_hybrid_rrf_search", {"p_org_id": "org", "p_embedding": q[qi].tolist(),
+                                                     "p_query": text, "p_limit": 20}).execute().data
+        _, Id, _ = CO.dense_topk_exact(x, q[qi:qi + 1], 40)
+        _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [terms], n, 40)
+        ei, es = O.fused_topk_ids(list(Il[0]), list(Id[0]), None, 20)
+        assert [r["child_id"] for r in rows] == [f"c{i}" for i in ei]
+        assert [r["rrf_score"] for r in rows] == [float(np.float32(s)) for s in es]
+        assert all((r["lexical_rank"] or r["semantic_rank"]) for r in rows)
+
+        class Emb:
+            def embed_query(self, text, _v=q[qi].tolist()):
+                return _v, None
+
+        hs = HybridSearcher("org", embedder=Emb(), config=SearchConfig(top_k_retrieve=50))._with(client)
+        out = asyncio.run(hs.search(text, top_k=10))
+        _, Id50, _ = CO.dense_topk_exact(x, q[qi:qi + 1], 50)
+        _, Il50 = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [terms], n, 50)
+        exp = O.legacy_rrf_fusion([[{"chunk_id": f"c{i}"} for i in Id50[0]],
+                                   [{"chunk_id": f"c{i}"} for i in Il50[0]]], 60)[:10]
+        assert [r.chunk_id for r in out] == [e["chunk_id"] for e in exp]
+        assert [r.rrf_score for r in out] == [e["rrf_score"] for e in exp]

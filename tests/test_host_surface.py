@@ -284,3 +284,51 @@ def test_standalone_fusion(golden):
         objs = [SSearchResult(final_score=v) for v in c["in"]]
         fus.normalize_scores(objs)
         assert [o.final_score for o in objs] == c["out"]
+
+
+def test_rule_based_planner_matches_reference(golden):
+    from triple_hybrid_rag_amd.core.query_planner import QueryPlanner
+    qp = QueryPlanner(RAGConfig())
+    for c in golden("simple_planner.json"):
+        plan = qp._simple_plan(c["query"])
+        assert plan.keywords == c["keywords"], c["query"]
+        assert (plan.requires_graph, plan.intent, plan.weights, plan.semantic_query_text,
+                plan.cypher_query) == (c["requires_graph"], c["intent"], c["weights"],
+                                       c["semantic_query_text"], c["cypher_query"])
+        assert [plan.lexical_top_k, plan.semantic_top_k, plan.graph_top_k] == c["top_ks"]
+    assert asyncio.run(qp.plan_async("Who works for Acme?")).requires_graph
+
+
+def test_legacy_hybrid_searcher_flow():
+    from triple_hybrid_rag_amd.retrieval.hybrid_search import HybridSearcher, SearchConfig
+
+    def row(i, **kw):
+        return {"id": f"k{i}", "content": f"c{i}", "modality": "text", "source_document": "docA" if i % 2 else "docB",
+                "page": None, "chunk_index": None, **kw}
+
+    class Backend:
+        def __init__(self):
+            self.calls = []
+
+        def rpc(self, name, params):
+            self.calls.append((name, params.get("p_limit")))
+            if name == "kb_chunks_vector_search":
+                rows = [row(i, similarity=1 - i / 10) for i in (1, 2, 3)]
+            else:
+                rows = [row(i, rank=5.0 - i) for i in (3, 1, 4)]
+            return _Reply(rows)
+
+    class Emb:
+        async def embed_query(self, q):
+            return [0.1, 0.2], None
+
+    hs = HybridSearcher("org", embedder=Emb(), config=SearchConfig(top_k_retrieve=7))
+    hs._supabase = be = Backend()
+    out = asyncio.run(hs.search("q", top_k=3))
+    assert be.calls == [("kb_chunks_vector_search", 7), ("kb_chunks_fts_pt", 7)]
+    # unweighted RRF, 0-based ranks: k1 = 1/61 + 1/62, k3 = 1/63 + 1/61; first-seen order on ties
+    assert [r.chunk_id for r in out] == ["k1", "k3", "k2"]
+    assert out[0].rrf_score == 1 / 61 + 1 / 62 and out[0].retrieval_method == "hybrid"
+    assert out[1].similarity_score == 0.7 and out[1].bm25_score == 2.0 and out[0].page == 1
+    only = asyncio.run(HybridSearcher("org", Emb(), SearchConfig(use_bm25=False))._with(be).search("q", source_document="docA"))
+    assert [r.chunk_id for r in only] == ["k1", "k3"] and only[0].retrieval_method == "vector"

@@ -137,7 +137,55 @@ class GpuIndexClient:
         if name == "rag2_lexical_search":
             return _Reply(self._lexical(params["p_query"], int(params.get("p_limit", 50)),
                                         params.get("p_collection")))
+        if name == "rag2_hybrid_rrf_search":
+            return _Reply(self._hybrid_rrf(params))
+        if name == "kb_chunks_vector_search":   # legacy RAG 1.0 (20260113_halfvec_4000.sql:70-105)
+            rows = self._semantic(params["p_embedding"], int(params.get("p_limit", 50)), None)
+            return _Reply([self._legacy_row(r, "similarity") for r in rows])
+        if name == "kb_chunks_fts_pt":          # legacy RAG 1.0 (20260113_add_kb_chunks.sql:152-190)
+            rows = self._lexical(params["p_query"], int(params.get("p_limit", 50)), None)
+            return _Reply([self._legacy_row(r, "rank") for r in rows])
         raise ValueError(f"unknown RPC {name!r}")
+
+    def _legacy_row(self, row: Dict[str, Any], score_key: str) -> Dict[str, Any]:
+        i = self.store.row_index(row["child_id"])
+        return {"id": row["child_id"], "content": row["text"], "modality": row["modality"],
+                "source_document": row["document_id"], "page": row["page"], "chunk_index": i,
+                "ocr_confidence": None, "is_table": row["modality"] == "table",
+                "table_context": None, "alt_text": None, "category": None, "title": None,
+                score_key: row[score_key]}
+
+    def _hybrid_rrf(self, params: Dict[str, Any]) -> List[Dict[str, Any]]:
+        """Server-side hybrid variant ``rag2_hybrid_rrf_search`` (rag2_schema.sql:413-496):
+        lexical and semantic top ``p_limit*2`` each, FULL OUTER JOIN on the chunk id,
+        ``w_l/(k+rank_l) + w_s/(k+rank_s)``, ORDER BY rrf_score DESC LIMIT p_limit -- one call,
+        fused on the device by thr_rrf_fuse (ties, unspecified in SQL, follow the RRF kernel's
+        sighting order)."""
+        limit = int(params.get("p_limit", 50))
+        coll = params.get("p_collection")
+        wide = min(N.THR_RRF_MAX_PER_CHANNEL, 2 * limit)
+        lex = self._lexical(params["p_query"], wide, coll)
+        sem = self._semantic(params["p_embedding"], wide, coll)
+
+        def ids(rows):
+            t = torch.full((1, max(len(rows), 1)), -1, dtype=torch.int64, device=self.index.device)
+            for j, r in enumerate(rows):
+                t[0, j] = self.store.doc_base + self.store.row_index(r["child_id"])
+            return t
+
+        if not lex and not sem:
+            return []
+        out_ids, out_sc, out_rk, cnt = N.rrf_fuse(
+            ids(lex), ids(sem), None, min(limit, 512), float(params.get("p_lexical_weight", 0.7)),
+            float(params.get("p_semantic_weight", 0.8)), 1.0, int(params.get("p_rrf_k", 60)),
+            want_ranks=True)
+        rows = []
+        for gid, sc, rk in zip(out_ids[0, : int(cnt[0])].tolist(), out_sc[0].tolist(), out_rk[0].tolist()):
+            row = self.store.result_row(int(gid) - self.store.doc_base)
+            row.update(rrf_score=float(np.float32(sc)), lexical_rank=rk[0] or None,
+                       semantic_rank=rk[1] or None)
+            rows.append(row)
+        return rows
 
     def _rows(self, ids, scores, count, score_key, collection, limit):
         out = []
