@@ -271,6 +271,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
 }
 
 }  // namespace thr
+// ---------------------------------------------------------------------------
+// Block -> (row slice, query tile) for the MFMA scans.
+// Every query tile streams the same rows, so the launch is laid out for the 8 private L2s:
+// workgroups are dealt round-robin over the XCDs (b and b+8 share one), and a 1-D grid of
+// 8 * m * n_qtiles blocks is decoded so that the blocks resident together on one XCD are the
+// n_qtiles query tiles of the SAME row slice.  They walk identical addresses in step: the
+// first one to ask for a line pulls it from HBM, the others hit it in that XCD's L2.  A 2-D
+// launch (gridDim.y > 1) keeps the plain (slice = x, query tile = y) layout.  Placement is a
+// speed matter only: any dispatch order gives the same result.
+// ---------------------------------------------------------------------------
+struct ScanSlot {
+    int qtile, slice, nslices;
+};
+__device__ __forceinline__ ScanSlot scan_slot(int n_qtiles) {
+    ScanSlot s;
+    if (gridDim.y > 1) {
+        s.qtile = blockIdx.y;
+        s.slice = blockIdx.x;
+        s.nslices = gridDim.x;
+    } else {
+        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+        s.qtile = j % n_qtiles;
+        s.slice = xcd + 8 * (j / n_qtiles);
+        s.nslices = gridDim.x / n_qtiles;
+    }
+    return s;
+}
+
 #include "dense_scan_mfma.hpp"
 #include "dense_scan_f16.hpp"
 namespace thr {
@@ -826,6 +854,53 @@ static int num_cus() {
     return g_num_cus;
 }
 
+// Grid of an MFMA scan (see scan_slot): 1-D, 8 * m * n_qtiles blocks, one block per CU.  m is
+// chosen for the fullest last round of blocks, the smallest such m first (fewer, longer row
+// slices; at 32 query tiles m = 1 and the whole launch is a single round).  THR_DENSE_MAP=grid
+// restores the plain 2-D launch (x = row slice, y = query tile) for comparison.
+static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_rows) {
+    static int plain = -1;
+    if (plain < 0) {
+        const char* e = getenv("THR_DENSE_MAP");
+        plain = (e && e[0] == 'g') ? 1 : 0;
+    }
+    const int cus = num_cus();
+    if (plain) {
+        int64_t blocks = (n_row_tiles + waves - 1) / waves;
+        if (blocks > cus) blocks = cus;
+        if (blocks < 1) blocks = 1;
+        *shared_rows = false;
+        return dim3((unsigned)blocks, (unsigned)ntiles);
+    }
+    int64_t m_max = n_row_tiles / (8 * (int64_t)waves);  // every wave gets at least one row tile
+    if (m_max < 1) m_max = 1;
+    if (m_max > 64) m_max = 64;
+    int best_m = 1;
+    double best_eff = 0.0;
+    for (int m = 1; m <= (int)m_max; ++m) {
+        const int64_t g = 8 * (int64_t)m * ntiles;
+        const int64_t rounds = (g + cus - 1) / cus;
+        const double eff = (double)g / (double)(rounds * cus);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best_m = m;
+        }
+    }
+    *shared_rows = ntiles > 1;
+    return dim3((unsigned)(8 * best_m * ntiles), 1u);
+}
+
+// row loads: non-temporal when no other query tile will ask for the same lines, plain when the
+// query tiles of a slice share them through L2.  THR_DENSE_NT=0|1 forces one flavour.
+static bool scan_nt(bool shared_rows) {
+    static int nt = -2;
+    if (nt == -2) {
+        const char* e = getenv("THR_DENSE_NT");
+        nt = e ? (e[0] == '0' ? 0 : 1) : -1;
+    }
+    return nt < 0 ? !shared_rows : nt == 1;
+}
+
 template <int MODE>
 static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
                        const float* queries, int n_queries, int ntiles, int64_t n_groups,
@@ -884,16 +959,10 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
         nw = lds2_for(8) <= 160 * 1024 ? 8 : 0;
     const bool v2 = nw != 0;
     const size_t lds = v2 ? lds2_for(nw) : lds1;
-    static int nt = -1;  // THR_DENSE_NT=0 turns the non-temporal row loads off
-    if (nt < 0) {
-        const char* e = getenv("THR_DENSE_NT");
-        nt = (e && e[0] == '0') ? 0 : 1;
-    }
     const int waves = v2 ? nw : MF_WAVES;
-    int64_t blocks = (n_row_tiles + waves - 1) / waves;
-    if (blocks > num_cus()) blocks = num_cus();  // one block per CU: the query tile fills LDS
-    if (blocks < 1) blocks = 1;
-    dim3 grid((unsigned)blocks, (unsigned)ntiles);
+    bool shared_rows = false;
+    const dim3 grid = scan_grid(ntiles, n_row_tiles, waves, &shared_rows);
+    const bool nt = scan_nt(shared_rows);
 #define THR_MF_LAUNCH(KERN, THREADS)                                                              \
     {                                                                                             \
         auto kern = KERN;                                                                         \
@@ -931,13 +1000,13 @@ static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_nor
     const int nq = f16_nq(dim);
     const size_t lds = f16_lds_bytes(dim, nq);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
-    int64_t blocks = (n_row_tiles + H_WAVES - 1) / H_WAVES;
-    if (blocks > num_cus()) blocks = num_cus();
-    if (blocks < 1) blocks = 1;
-    dim3 grid((unsigned)blocks, (unsigned)ntiles);
+    bool shared_rows = false;
+    const dim3 grid = scan_grid(ntiles, n_row_tiles, H_WAVES, &shared_rows);
+    const bool nt = scan_nt(shared_rows);
 #define THR_H_CASE(DIM)                                                                           \
     case DIM: {                                                                                   \
-        auto kern = nq == 2 ? dense_scan_f16<DIM, MODE, true, 2> : dense_scan_f16<DIM, MODE, true, 1>; \
+        auto kern = nq == 2 ? (nt ? dense_scan_f16<DIM, MODE, true, 2> : dense_scan_f16<DIM, MODE, false, 2>) \
+                            : (nt ? dense_scan_f16<DIM, MODE, true, 1> : dense_scan_f16<DIM, MODE, false, 1>); \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \

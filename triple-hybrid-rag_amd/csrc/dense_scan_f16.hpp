@@ -36,7 +36,8 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     static_assert(QT <= (1 << QBITS), "query-in-tile index must fit the packed candidate word");
     extern __shared__ float4 lds_q[];  // [QT][CPR] f16 queries | H_WAVES stage tiles | H_WAVES wbufs
 
-    const int qtile = blockIdx.y;
+    const ScanSlot slot = scan_slot((n_queries + QT - 1) / QT);
+    const int qtile = slot.qtile;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 #pragma unroll
     for (int s = 0; s < NQ; ++s)
         my_tau[s] = MODE == MODE_FILTER ? tau[qtile * QT + 32 * s + r] : 0.f;
-    const int64_t wave_id = (int64_t)blockIdx.x * H_WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * H_WAVES;
+    const int64_t wave_id = (int64_t)slot.slice * H_WAVES + wave;
+    const int64_t wave_stride = (int64_t)slot.nslices * H_WAVES;
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs16);
 
     const int lrow = lane >> 3, lchunk = lane & 7;

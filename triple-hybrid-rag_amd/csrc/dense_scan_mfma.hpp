@@ -59,7 +59,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
     constexpr int CPR = D / 4;  // 16-byte chunks per row
     extern __shared__ float4 lds_q[];  // [MF_QT][CPR] swizzled, then MF_WAVES * WBUF staging slots
 
-    const int qtile = blockIdx.y;
+    const ScanSlot slot = scan_slot((n_queries + MF_QT - 1) / MF_QT);
+    const int qtile = slot.qtile;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
     __syncthreads();
 
     const float my_tau = MODE == MODE_FILTER ? tau[qtile * MF_QT + r] : 0.f;
-    const int64_t wave_id = (int64_t)blockIdx.x * MF_WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * MF_WAVES;
+    const int64_t wave_id = (int64_t)slot.slice * MF_WAVES + wave;
+    const int64_t wave_stride = (int64_t)slot.nslices * MF_WAVES;
     const float4* docs4 = reinterpret_cast<const float4*>(docs);
 
 #define THR_PIN(x) asm volatile("" : "+v"(x))
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
     static_assert(D % 128 == 0 && NG >= 2, "dim must be a multiple of 128, >= 256");
     extern __shared__ float4 lds_q[];  // [32][CPR] queries | NW stage tiles | NW wbufs
 
-    const int qtile = blockIdx.y;
+    const ScanSlot slot = scan_slot((n_queries + MF_QT - 1) / MF_QT);
+    const int qtile = slot.qtile;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
     __syncthreads();
 
     const float my_tau = MODE == MODE_FILTER ? tau[qtile * MF_QT + r] : 0.f;
-    const int64_t wave_id = (int64_t)blockIdx.x * NW + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * NW;
+    const int64_t wave_id = (int64_t)slot.slice * NW + wave;
+    const int64_t wave_stride = (int64_t)slot.nslices * NW;
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
 
     // loader role of this lane: row (lane >> 3) + 8*i of the tile, 16-byte chunk (lane & 7)
