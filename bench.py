@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-f16-extra", action="store_true",
                     help="skip the additional float16-shortlist measurement reported next to the "
                          "default float32-scan one")
-    ap.add_argument("--shortlist", choices=("f32", "f16"), default="f32",
+    ap.add_argument("--shortlist", choices=("f32", "f16", "f16-inline"), default="f32",
                     help="f16: opt-in float16 shortlist copy for the streaming pass (results stay "
                          "float64-exact; see DESIGN.md 4.1b)")
     return ap.parse_args()
@@ -126,6 +126,8 @@ def main():
         ms = ev0.elapsed_time(ev1) / args.probe_reps
         if f16:
             qt, elem, name = (64 if args.dim <= 768 else 32), 2, "dense_scan_f16"
+            if index.docs16 is None:
+                elem, name = 4, "dense_scan_f16<F32IN>"
         else:
             qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
             elem = 4
@@ -143,7 +145,7 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events around the scan alone ----
     n_local = hi - lo
-    f16 = args.shortlist == "f16"
+    f16 = args.shortlist != "f32"
     roofline, qt, tiles = probe_scan(f16)
 
     def pmc_traffic(kind, qt_expected, ntiles):

@@ -98,25 +98,31 @@ int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs,
                          uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                          thr_stream_t stream);
 
-/* Opt-in: shortlist scan over a float16 COPY of the corpus (half the HBM bytes per pass,
- * f16 MFMA, 64 queries per pass).  The float32 corpus stays the source of truth: scores are
- * the same float64 rescoring of float32 rows, and the certificate's error bound additionally
- * covers row quantisation (doc_rel_err = max_d ||d16-d||/||d||, measured by
- * thr_dense_quantize_f16 into *max_rel_err, a DEVICE float) and query quantisation (measured
- * per query on the device).  dim in {512, 768, 1024}; |values| must be < 65504. */
+/* Shortlist scan on the f16 matrix cores (64 queries per pass at dim <= 768).  The float32
+ * corpus stays the source of truth: scores are the same float64 rescoring of float32 rows, and
+ * the certificate's error bound additionally covers row quantisation (doc_rel_err =
+ * max_d ||d16-d||/||d||, measured by thr_dense_quantize_f16 into *max_rel_err, a DEVICE float)
+ * and query quantisation (measured per query on the device).  Two flavours:
+ *   docs16 != NULL: the scan streams a float16 COPY of the rows (half the bytes per row);
+ *   docs16 == NULL: the scan streams the float32 rows and rounds them to float16 in registers
+ *                   (no second copy; thr_dense_quantize_f16 with docs16 == NULL only measures
+ *                   doc_rel_err).
+ * dim in {512, 768, 1024}; |values| must be < 65504 (doc_rel_err is +inf otherwise and
+ * thr_dense_topk_f16 rejects it). */
 int thr_dense_quantize_f16(const float *docs, int64_t n_docs, int dim,
-                           uint16_t *docs16 /* f16 [n_docs, dim] */, float *max_rel_err,
+                           uint16_t *docs16 /* f16 [n_docs, dim] or NULL */, float *max_rel_err,
                            thr_stream_t stream);
 size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries, int kprime);
-int thr_dense_topk_f16(const float *docs, const uint16_t *docs16, double doc_rel_err,
+int thr_dense_topk_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
                        const double *dnorm, const float *inv_norm, int64_t n_docs, int dim,
                        int64_t id_base, const float *queries, int n_queries, int k, int kprime,
                        double *out_scores, int64_t *out_ids, int32_t *out_counts,
                        uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                        thr_stream_t stream);
-int thr_dense_scan_probe_f16(const uint16_t *docs16, const float *inv_norm, int64_t n_docs,
-                             int dim, const float *queries, int n_queries, void *workspace,
-                             size_t workspace_bytes, thr_stream_t stream);
+int thr_dense_scan_probe_f16(const float *docs, const uint16_t *docs16 /* or NULL */,
+                             const float *inv_norm, int64_t n_docs, int dim, const float *queries,
+                             int n_queries, void *workspace, size_t workspace_bytes,
+                             thr_stream_t stream);
 
 /* Timing/roofline probe: ONLY the streaming pass-1 kernel of thr_dense_topk
  * (threshold filter against ``tau``), for ``n_tiles`` query tiles. */

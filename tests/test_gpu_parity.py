@@ -408,10 +408,12 @@ def test_dropin_retrieve_end_to_end(T):
         SETTINGS.__dict__.update(saved)
 
 
+@pytest.mark.parametrize("mode", ["f16", "f16-inline"])
 @pytest.mark.parametrize("n,d", [(50000, 768), (20000, 1024), (4000, 512)])
-def test_dense_f16_shortlist_is_still_exact(T, n, d):
-    """Opt-in float16 shortlist copy: results must be the SAME bits as the float32 oracle
-    (scores come from float64 rescoring of float32 rows; the certificate covers quantisation)."""
+def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
+    """Shortlist on the f16 matrix cores (from a float16 copy, or from float32 rows rounded in
+    registers): results must be the SAME bits as the float32 oracle (scores come from float64
+    rescoring of float32 rows; the certificate covers quantisation)."""
     x, rng = rand_docs(n, d, 77)
     x[13] = 0
     x[200:230] = x[199]                      # 31-way tie inside the top-100 of query 0
@@ -419,10 +421,13 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d):
     q[0] = x[199] + 0.05 * q[0]
     q[::2] = x[rng.integers(0, n, 35)] + 0.5 * q[::2]
     q[5] = 0
-    idx = T.GpuIndex(doc_base=123).set_dense(x, shortlist="f16")
+    idx = T.GpuIndex(doc_base=123).set_dense(x, shortlist=mode)
     assert 0 < idx.doc_rel_err < 6e-4        # ~2^-12/sqrt(3) typical, 2^-11 worst case
-    x16 = idx.docs16.cpu().numpy()
-    assert np.array_equal(x16, x.astype(np.float16))
+    x16 = x.astype(np.float16)
+    if mode == "f16":
+        assert np.array_equal(idx.docs16.cpu().numpy(), x16)
+    else:
+        assert idx.docs16 is None            # no second copy of the corpus
     nz = x.any(axis=1)
     rel = (np.linalg.norm(x16.astype(np.float64) - x, axis=1)[nz]
            / np.linalg.norm(x.astype(np.float64), axis=1)[nz])
@@ -502,7 +507,20 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
         assert list(ids[i]) == ei and list(sc[i]) == es
 
 
-@pytest.mark.parametrize("shortlist", ["f32", "f16"])
+def test_dense_f16_rejects_rows_outside_half_range(T):
+    x, _ = rand_docs(3000, 768, 5)
+    x[17, 3] = 1e6                            # rounds to +inf in float16
+    for mode in ("f16", "f16-inline"):
+        with pytest.raises(T._native.NativeError, match="float16"):
+            T.GpuIndex().set_dense(x, shortlist=mode)
+    idx = T.GpuIndex().set_dense(x, shortlist="f32")
+    q = x[:4].copy()
+    S, I, cnt, _ = idx.dense_search(dev(q), 10)
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 10)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "wide-range rows")
+
+
+@pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
 def test_dense_edge_shapes_and_near_ties(T, shortlist):
     rng = np.random.default_rng(31)
     # tiny corpora, k > n, single query, k = 1

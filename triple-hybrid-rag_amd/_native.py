@@ -51,7 +51,7 @@ _SIGNATURES = {
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
                              _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32]),
@@ -218,14 +218,14 @@ def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
            "thr_dense_scan_probe")
 
 
-def dense_quantize_f16(docs: torch.Tensor):
-    """-> (docs16 f16 [n, D], max relative row error as a Python float)."""
+def dense_quantize_f16(docs: torch.Tensor, keep_copy: bool = True):
+    """-> (docs16 f16 [n, D] or None, max relative row error of the rounding as a float)."""
     p = _dev(docs, torch.float32, "docs", 2)
     n, d = docs.shape
-    d16 = torch.empty((n, d), dtype=torch.float16, device=docs.device)
+    d16 = torch.empty((n, d), dtype=torch.float16, device=docs.device) if keep_copy else None
     err = torch.zeros(1, dtype=torch.float32, device=docs.device)
-    _check(load().thr_dense_quantize_f16(p, n, d, d16.data_ptr(), err.data_ptr(), _stream()),
-           "thr_dense_quantize_f16")
+    _check(load().thr_dense_quantize_f16(p, n, d, d16.data_ptr() if keep_copy else None,
+                                         err.data_ptr(), _stream()), "thr_dense_quantize_f16")
     return d16, float(err.item())
 
 
@@ -236,9 +236,9 @@ def dense_f16_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int
 def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k: int,
                    kprime: int, id_base: int = 0, workspace: Optional[torch.Tensor] = None):
     pd = _dev(docs, torch.float32, "docs", 2)
-    ph = _dev(docs16, torch.float16, "docs16", 2)
+    ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
     n, d = docs.shape
-    if tuple(docs16.shape) != (n, d):
+    if docs16 is not None and tuple(docs16.shape) != (n, d):
         raise NativeError("docs16 shape != docs shape")
     pq = _dev(queries, torch.float32, "queries", 2)
     nq = queries.shape[0]
@@ -261,15 +261,16 @@ def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k
     return S, I, cnt, flg
 
 
-def dense_scan_probe_f16(docs16, inv_norm, queries, workspace: torch.Tensor) -> None:
-    ph = _dev(docs16, torch.float16, "docs16", 2)
-    n, d = docs16.shape
+def dense_scan_probe_f16(docs, docs16, inv_norm, queries, workspace: torch.Tensor) -> None:
+    pd = _dev(docs, torch.float32, "docs", 2)
+    ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
+    n, d = docs.shape
     pq = _dev(queries, torch.float32, "queries", 2)
     if queries.shape[1] != d or inv_norm.shape[0] != n:
         raise NativeError("probe: shape mismatch")
     pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
     pw = _dev(workspace, workspace.dtype, "workspace")
-    _check(load().thr_dense_scan_probe_f16(ph, pi, n, d, pq, queries.shape[0], pw,
+    _check(load().thr_dense_scan_probe_f16(pd, ph, pi, n, d, pq, queries.shape[0], pw,
                                            workspace.numel() * workspace.element_size(),
                                            _stream()), "thr_dense_scan_probe_f16")
 

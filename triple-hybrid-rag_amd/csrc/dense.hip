@@ -992,8 +992,10 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
     return launch_status();
 }
 
+// rows16 != nullptr: stream the float16 copy; else stream the float32 rows and round in flight
 template <int MODE>
-static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_norm, int64_t n_docs,
+static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
+                           const float* inv_norm, int64_t n_docs,
                            const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
                            int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
@@ -1003,26 +1005,40 @@ static int launch_scan_f16(int dim, const _Float16* docs16, const float* inv_nor
     bool shared_rows = false;
     const dim3 grid = scan_grid(ntiles, n_row_tiles, H_WAVES, &shared_rows);
     const bool nt = scan_nt(shared_rows);
-#define THR_H_CASE(DIM)                                                                           \
-    case DIM: {                                                                                   \
-        auto kern = nq == 2 ? (nt ? dense_scan_f16<DIM, MODE, true, 2> : dense_scan_f16<DIM, MODE, false, 2>) \
-                            : (nt ? dense_scan_f16<DIM, MODE, true, 1> : dense_scan_f16<DIM, MODE, false, 1>); \
+    const bool f32_in = rows16 == nullptr;
+    const void* rows = f32_in ? (const void*)rows32 : (const void*)rows16;
+#define THR_H_LAUNCH(KERN)                                                                        \
+    {                                                                                             \
+        auto kern = KERN;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, docs16, inv_norm, n_docs,        \
-                           queries, n_queries, n_row_tiles, tile_stride, tau, tile_cnt,           \
-                           tile_list, tile_cap, sample, sample_ld);                               \
-        break;                                                                                    \
+        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, rows, inv_norm, n_docs, queries, \
+                           n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
+                           tile_cap, sample, sample_ld);                                          \
     }
-    switch (dim) {
-        THR_H_CASE(512)
-        THR_H_CASE(768)
-        THR_H_CASE(1024)
+#define THR_H_CASE(DIM, NQV)                                                                      \
+    case DIM:                                                                                     \
+        if (f32_in) {                                                                             \
+            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, true>))                    \
+            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, true>))                      \
+        } else {                                                                                  \
+            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, false>))                   \
+            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, false>))                     \
+        }                                                                                         \
+        break;
+    static_assert(sizeof(_Float16) * 64 * 768 + (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES <= 160 * 1024,
+                  "two query sub-tiles fit at dim 768");
+    switch (dim) {  // the sub-tile count is f16_nq(dim)
+        THR_H_CASE(512, 2)
+        THR_H_CASE(768, 2)
+        THR_H_CASE(1024, 1)
         default:
             return THR_ERR_UNSUPPORTED;
     }
 #undef THR_H_CASE
+#undef THR_H_LAUNCH
+    (void)nq;
     return launch_status();
 }
 
@@ -1056,25 +1072,27 @@ extern "C" size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queri
     return make_plan(n_docs, n_queries, kprime).total;
 }
 
-// K1..K4 for either scan flavour.  docs16 == nullptr: float32 scan.
+// K1..K4 for every scan flavour.  p.kind == KIND_F32: float32 MFMA scan; KIND_F16: f16 MFMA scan
+// over docs16, or over the float32 rows rounded in flight when docs16 == nullptr.
 static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16* docs16,
                           double doc_relerr, const double* dnorm, const float* inv_norm,
                           int64_t n_docs, int dim, int64_t id_base, const float* queries,
                           int n_queries, int k, int kprime, double* out_scores, int64_t* out_ids,
                           int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st) {
     float* tau = (float*)(ws + p.off_tau);
-    float* qerr = docs16 ? (float*)(ws + p.off_qerr) : nullptr;
+    const bool h = p.kind == KIND_F16;
+    float* qerr = h ? (float*)(ws + p.off_qerr) : nullptr;
     int* cnt = (int*)(ws + p.off_cnt);
     int* tcnt = (int*)(ws + p.off_tcnt);
     Cand* cand = (Cand*)(ws + p.off_cand);
     Cand* tlist = (Cand*)(ws + p.off_tlist);
     float* sample = (float*)(ws + p.off_sample);
     auto scan = [&](bool all, int64_t units, int64_t stride, float* smp, int64_t ld) -> int {
-        if (docs16)
-            return all ? launch_scan_f16<MODE_ALL>(dim, docs16, inv_norm, n_docs, queries, n_queries,
-                                                   p.ntiles, units, stride, nullptr, nullptr,
-                                                   nullptr, 0, smp, ld, st)
-                       : launch_scan_f16<MODE_FILTER>(dim, docs16, inv_norm, n_docs, queries,
+        if (h)
+            return all ? launch_scan_f16<MODE_ALL>(dim, docs, docs16, inv_norm, n_docs, queries,
+                                                   n_queries, p.ntiles, units, stride, nullptr,
+                                                   nullptr, nullptr, 0, smp, ld, st)
+                       : launch_scan_f16<MODE_FILTER>(dim, docs, docs16, inv_norm, n_docs, queries,
                                                       n_queries, p.ntiles, units, stride, tau, tcnt,
                                                       tlist, p.tile_cap, nullptr, 0, st);
         return all ? launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
@@ -1101,7 +1119,7 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                        tlist, p.tile_cap, p.qtile, p.row_bits, cnt, cand);
     if ((rc = launch_status())) return rc;
     const double u = 5.9604644775390625e-08;
-    const double eps32 = docs16 ? ((double)dim + 16.0) * u : scan_eps(dim);
+    const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
     hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS),
                        sizeof(float) * dim + sizeof(float4) * SEL_THREADS * 9, st,
                        docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
@@ -1149,7 +1167,7 @@ extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_q
 extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim, uint16_t* docs16,
                                       float* max_rel_err, thr_stream_t stream) {
     clear_status();
-    THR_RETURN_IF(!docs || !docs16 || !max_rel_err || n_docs <= 0 || dim <= 0, THR_ERR_INVALID);
+    THR_RETURN_IF(!docs || !max_rel_err || n_docs <= 0 || dim <= 0, THR_ERR_INVALID);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(max_rel_err, 0, sizeof(float), st);
     if (e != hipSuccess) return (int)e;
@@ -1169,7 +1187,7 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
     int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
                            out_flags, workspace, n_docs, n_queries, k, kprime);
     if (rc) return rc;
-    THR_RETURN_IF(!docs16 || !(doc_rel_err >= 0.0), THR_ERR_INVALID);
+    THR_RETURN_IF(!(doc_rel_err >= 0.0) || !(doc_rel_err < 1.0), THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim);
@@ -1201,12 +1219,13 @@ extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, in
                                         p.tile_cap, nullptr, 0, st);
 }
 
-extern "C" int thr_dense_scan_probe_f16(const uint16_t* docs16, const float* inv_norm,
+extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs16,
+                                        const float* inv_norm,
                                         int64_t n_docs, int dim, const float* queries,
                                         int n_queries, void* workspace, size_t workspace_bytes,
                                         thr_stream_t stream) {
     clear_status();
-    THR_RETURN_IF(!docs16 || !inv_norm || !queries || !workspace, THR_ERR_INVALID);
+    THR_RETURN_IF((!docs16 && !docs) || !inv_norm || !queries || !workspace, THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS_F16 || n_queries <= 0,
                   THR_ERR_INVALID);
@@ -1216,7 +1235,7 @@ extern "C" int thr_dense_scan_probe_f16(const uint16_t* docs16, const float* inv
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
-    return launch_scan_f16<MODE_FILTER>(dim, reinterpret_cast<const _Float16*>(docs16), inv_norm,
+    return launch_scan_f16<MODE_FILTER>(dim, docs, reinterpret_cast<const _Float16*>(docs16), inv_norm,
                                         n_docs, queries, n_queries, p.ntiles, p.groups, 1,
                                         (const float*)(ws + p.off_tau), (int*)(ws + p.off_tcnt),
                                         (Cand*)(ws + p.off_tlist), p.tile_cap, nullptr, 0, st);

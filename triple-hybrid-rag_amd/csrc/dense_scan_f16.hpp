@@ -1,4 +1,7 @@
-// Shortlist scan over a float16 COPY of the corpus (opt-in: thr_dense_topk_f16).
+// Shortlist scan on the f16 matrix cores (thr_dense_topk_f16), in two flavours:
+//   F32IN = false: streams a float16 COPY of the corpus (half the bytes per row);
+//   F32IN = true : streams the float32 rows themselves and rounds them to float16 in registers
+//                  on the way into the LDS transpose tile -- no second copy of the corpus.
 //
 // The float32 corpus stays the source of truth: every returned score is the float64
 // rescoring of float32 rows, and the top-k is certified with an error bound that now
@@ -22,14 +25,31 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int H_WAVES = 8;
 constexpr int H_THREADS = H_WAVES * WAVE;
 
-template <int DIM, int MODE, bool nt_loads, int NQ>  // NQ = query sub-tiles of 32 (1 or 2)
+// round 8 floats to nearest-even float16 (same rounding as quantize_f16, whose error bound covers
+// both flavours)
+__device__ __forceinline__ f32x4 pack_f16x8(f32x4 lo, f32x4 hi) {
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const half4 a = __builtin_convertvector(lo, half4), b = __builtin_convertvector(hi, half4);
+    half8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// NQ = query sub-tiles of 32 (1 or 2).  With F32IN a stage (64 dims of 32 rows) is 8 KiB of
+// float32: each lane loads float4 #c and #(8+c) of its row's 16 (two fully coalesced 128-byte
+// row segments per 8 lanes) and packs them into ONE 16-byte f16 chunk, i.e. chunk c of a stage
+// holds dims {4c..4c+3, 32+4c..32+4c+3}.  The query tile is laid out with the same permutation;
+// k is only a summation index, so the dot products are unchanged.  The register ring then holds
+// 2 stages instead of 4 (the same 16 KiB in flight per wave).
+template <int DIM, int MODE, bool nt_loads, int NQ, bool F32IN = false>
 __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
-    const _Float16* __restrict__ docs16, const float* __restrict__ inv_norm, int64_t n_docs,
+    const void* __restrict__ docs16, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
     const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
     int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
     constexpr int QT = 32 * NQ;
     constexpr int CPR = DIM / 8;   // 16-byte chunks (8 halves) per row
+    constexpr int GPR = F32IN ? DIM / 4 : DIM / 8;  // 16-byte chunks per row in global memory
+    constexpr int GSTEP = F32IN ? 16 : 8;           // ... per stage
     constexpr int NG = DIM / 256;  // groups of 4 stages of 64 dims
     constexpr int QBITS = 32 - ROW_BITS_F16;
     static_assert(DIM % 256 == 0 && NG >= 2, "f16 scan needs dim % 256 == 0 and dim >= 512");
@@ -63,8 +83,12 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
         if (qg < n_queries) {
-            const float4* src = reinterpret_cast<const float4*>(queries + (int64_t)qg * DIM + 8 * c);
-            const float4 lo = src[0], hi = src[1];
+            // dims of chunk c: 8c..8c+7, or (F32IN) the two float4 the row loader pairs up
+            const int d_lo = F32IN ? 64 * (c >> 3) + 4 * (c & 7) : 8 * c;
+            const int d_hi = F32IN ? d_lo + 32 : d_lo + 4;
+            const float* qsrc = queries + (int64_t)qg * DIM;
+            const float4 lo = *reinterpret_cast<const float4*>(qsrc + d_lo);
+            const float4 hi = *reinterpret_cast<const float4*>(qsrc + d_hi);
             v[0] = (_Float16)lo.x; v[1] = (_Float16)lo.y; v[2] = (_Float16)lo.z; v[3] = (_Float16)lo.w;
             v[4] = (_Float16)hi.x; v[5] = (_Float16)hi.y; v[6] = (_Float16)hi.z; v[7] = (_Float16)hi.w;
         }
@@ -84,7 +108,7 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     auto load_off = [&](int64_t t, int i) -> int64_t {
         int64_t row = t * tile_stride * MF_ROWS + lrow + 8 * i;
         row = row < n_docs ? row : n_docs - 1;
-        return row * CPR + lchunk;
+        return row * GPR + lchunk;
     };
     int wslot0 = mf2_slot(lrow, lchunk), wslot1 = mf2_slot(lrow + 8, lchunk);
     int wslot2 = mf2_slot(lrow + 16, lchunk), wslot3 = mf2_slot(lrow + 24, lchunk);
@@ -103,16 +127,16 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 
 #define THR_PIN(x) asm volatile("" : "+v"(x))
 #define HS_LD(ptr) (nt_loads ? __builtin_nontemporal_load(&docs4[ptr]) : docs4[ptr])
-#define HS_LOAD(dst)                                       \
-    THR_PIN(p0); dst[0] = HS_LD(p0); p0 += 8;              \
-    THR_PIN(p1); dst[1] = HS_LD(p1); p1 += 8;              \
-    THR_PIN(p2); dst[2] = HS_LD(p2); p2 += 8;              \
-    THR_PIN(p3); dst[3] = HS_LD(p3); p3 += 8;
-#define HS_STORE(src)                               \
-    THR_PIN(wslot0); stage[wslot0] = src[0];        \
-    THR_PIN(wslot1); stage[wslot1] = src[1];        \
-    THR_PIN(wslot2); stage[wslot2] = src[2];        \
-    THR_PIN(wslot3); stage[wslot3] = src[3];
+#define HS_LOAD1(dst, i, p)                                             \
+    THR_PIN(p); dst[i] = HS_LD(p);                                      \
+    if constexpr (F32IN) dst[4 + i] = HS_LD(p + 8);                     \
+    p += GSTEP;
+#define HS_LOAD(dst) HS_LOAD1(dst, 0, p0) HS_LOAD1(dst, 1, p1) HS_LOAD1(dst, 2, p2) HS_LOAD1(dst, 3, p3)
+#define HS_STORE1(src, i, ws)                                           \
+    THR_PIN(ws);                                                        \
+    if constexpr (F32IN) stage[ws] = pack_f16x8(src[i], src[4 + i]);    \
+    else stage[ws] = src[i];
+#define HS_STORE(src) HS_STORE1(src, 0, wslot0) HS_STORE1(src, 1, wslot1) HS_STORE1(src, 2, wslot2) HS_STORE1(src, 3, wslot3)
     // 1 + NQ LDS reads per quad: the row fragment and one query fragment per sub-tile.
     // qoff = chunk offset (in 16-byte units) of the stage's first chunk group (multiple of 16).
 #define HS_READ(F, quadslot, qoff, par, quad)                                                  \
@@ -156,15 +180,18 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     f0.a = f1.a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NQ; ++s) f0.b[s] = f1.b[s] = f0.a;
-    f32x4 ring0[4], ring1[4], ring2[4], ring3[4];
+    constexpr int RW = F32IN ? 8 : 4;  // registers per ring slot
+    f32x4 ring0[RW], ring1[RW], ring2[RW], ring3[RW];
     int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int64_t t = wave_id;
     if (t < n_tiles) {
         p0 = load_off(t, 0); p1 = load_off(t, 1); p2 = load_off(t, 2); p3 = load_off(t, 3);
         HS_LOAD(ring0)
         HS_LOAD(ring1)
-        HS_LOAD(ring2)
-        HS_LOAD(ring3)
+        if constexpr (!F32IN) {
+            HS_LOAD(ring2)
+            HS_LOAD(ring3)
+        }
         HS_STORE(ring0)
         HS_LOAD(ring0)
         HS_READ(f0, 0, 0, 0, 0)
@@ -189,11 +216,22 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
         for (int g = 0; g < NG; ++g) {
             const int qb = 32 * g;                      // chunk offset of stages 4g, 4g+1
             const int qn = g + 1 < NG ? qb + 32 : 0;    // first chunks of the next group / tile
-            HS_STAGE(0, ring1, qb, qb)
-            HS_STAGE(1, ring2, qb, qb + 16)
-            HS_STAGE(2, ring3, qb + 16, qb + 16)
-            if (g == NG - 2) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
-            HS_STAGE(3, ring0, qb + 16, qn)
+            if constexpr (!F32IN) {
+                // ring of 4: the refill issued in stage u is stage 4g+u+5
+                HS_STAGE(0, ring1, qb, qb)
+                HS_STAGE(1, ring2, qb, qb + 16)
+                HS_STAGE(2, ring3, qb + 16, qb + 16)
+                if (g == NG - 2) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
+                HS_STAGE(3, ring0, qb + 16, qn)
+            } else {
+                // ring of 2: the refill issued in stage u is stage 4g+u+3 -- from u = 1 of the
+                // last group on, that is the head of the wave's next row tile
+                HS_STAGE(0, ring1, qb, qb)
+                if (g == NG - 1) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
+                HS_STAGE(1, ring0, qb, qb + 16)
+                HS_STAGE(2, ring1, qb + 16, qb + 16)
+                HS_STAGE(3, ring0, qb + 16, qn)
+            }
         }
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
@@ -229,7 +267,9 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 #undef HS_WAIT2
 #undef HS_READ
 #undef HS_STORE
+#undef HS_STORE1
 #undef HS_LOAD
+#undef HS_LOAD1
 #undef HS_LD
 #undef THR_PIN
     if constexpr (MODE == MODE_FILTER) {
@@ -251,7 +291,7 @@ __global__ __launch_bounds__(256) void quantize_f16(const float* __restrict__ do
     for (int i = lane; i < dim; i += WAVE) {
         const float v = x[i];
         const _Float16 hv = (_Float16)v;
-        y[i] = hv;
+        if (docs16) y[i] = hv;  // docs16 == nullptr: measure only
         const double d = (double)v - (double)(float)hv;
         err += d * d;
         nrm += (double)v * (double)v;

@@ -48,6 +48,7 @@ class GpuIndex:
         self.dim = 0
         self.docs = self.dnorm = self.inv_norm = self.docs16 = None
         self.doc_rel_err = 0.0
+        self.shortlist = "f32"
         self.lex = None
         self.graph = None
         self.tokens = None
@@ -59,18 +60,27 @@ class GpuIndex:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
+    SHORTLISTS = ("f32", "f16", "f16-inline")
+
     def set_dense(self, docs, shortlist: str = "f32") -> "GpuIndex":
-        """shortlist="f16" additionally keeps a float16 copy of the rows for the streaming
-        pass (half the bytes per pass, 64 queries per pass); scores still come from the
-        float64 rescoring of the float32 rows and the certificate covers the quantisation."""
-        if shortlist not in ("f32", "f16"):
-            raise ValueError("shortlist must be 'f32' or 'f16'")
+        """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
+        rescoring of the float32 rows, and the per-query certificate covers the scan's error):
+          "f32"        float32 rows on the fp32 matrix cores (32 queries per pass);
+          "f16-inline" float32 rows rounded to float16 in registers, f16 matrix cores
+                       (64 queries per pass, no extra memory);
+          "f16"        additionally keeps a float16 copy of the rows and streams that."""
+        if shortlist not in self.SHORTLISTS:
+            raise ValueError(f"shortlist must be one of {self.SHORTLISTS}")
         self.docs = self._t(docs, torch.float32)
         self.n_docs, self.dim = self.docs.shape
         self.dnorm, self.inv_norm = N.doc_norms(self.docs)
         self.docs16, self.doc_rel_err = (None, 0.0)
-        if shortlist == "f16":
-            self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs)
+        self.shortlist = shortlist
+        if shortlist != "f32":
+            self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
+                                                                 keep_copy=shortlist == "f16")
+            if not np.isfinite(self.doc_rel_err):
+                raise N.NativeError("rows do not fit float16 (|value| >= 65504): use shortlist='f32'")
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
@@ -106,7 +116,7 @@ class GpuIndex:
         fp32-error certificate cannot prove exact (massive ties / duplicates) are redone on
         the exhaustive float64 path; that check reads the flags back (one sync per batch)."""
         queries = self._t(queries, torch.float32)
-        if self.docs16 is not None:
+        if self.shortlist != "f32":
             # tau must sit clearly below the k-th score for the quantisation-aware certificate:
             # k' = 192 puts it ~6e-3 below on a 1M-row corpus, ~6x the f16 error bound
             kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 92)))
@@ -135,8 +145,8 @@ class GpuIndex:
         if self._ws is None:
             raise N.NativeError("scan_probe needs a preceding dense_search on this index")
         queries = self._t(queries, torch.float32)
-        if self.docs16 is not None:
-            N.dense_scan_probe_f16(self.docs16, self.inv_norm, queries, self._ws)
+        if self.shortlist != "f32":
+            N.dense_scan_probe_f16(self.docs, self.docs16, self.inv_norm, queries, self._ws)
         else:
             N.dense_scan_probe(self.docs, self.inv_norm, queries, self._ws)
 
