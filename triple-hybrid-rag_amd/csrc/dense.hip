@@ -386,6 +386,88 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
     return prefix;
 }
 
+// ---------------------------------------------------------------------------
+// Two-pass LOWER BOUND of the kk-th largest key: 12-bit digits over the top 24 key bits, the
+// low 8 bits of the result are zero.  For a float key that is a value at most 2^-15 (relative)
+// below the true kk-th -- all a threshold needs (it only has to let the top kk through), at
+// half the passes of the exact select.  key(i) is evaluated for i in [0, n); the bins of a pass
+// are searched by all threads (per-thread partial sums + one wave scan).
+// hist = 4096 ints of LDS, aux = 8 ints of LDS.  blockDim.x must be 256.
+// ---------------------------------------------------------------------------
+constexpr int CS_BINS = 4096;
+__device__ __forceinline__ void coarse_find_bin(const int* hist, int remaining, int* aux) {
+    // thread t owns the 16 bins [4096 - 16(t+1), 4096 - 16t): t = 0 holds the largest keys
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int top = CS_BINS - 16 * t;
+    int mine = 0;
+#pragma unroll
+    for (int b = 1; b <= 16; ++b) mine += hist[top - b];
+    int incl = mine;  // inclusive scan over t within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) aux[4 + w] = incl;
+    if (t == 0) aux[0] = 0, aux[1] = -1;
+    __syncthreads();
+    int before = 0;
+    for (int x = 0; x < w; ++x) before += aux[4 + x];
+    incl += before;
+    const int excl = incl - mine;
+    if (excl < remaining && remaining <= incl) {
+        int cum = excl, b = top - 1;
+        for (; b > top - 16; --b) {
+            if (cum + hist[b] >= remaining) break;
+            cum += hist[b];
+        }
+        aux[0] = b;
+        aux[1] = cum;
+    }
+    __syncthreads();
+    if (aux[1] < 0) {  // fewer than `remaining` keys in all: bin 0 (cannot happen for kk <= n)
+        if (t == 255) aux[0] = 0, aux[1] = incl - hist[0];
+        __syncthreads();
+    }
+}
+
+template <typename KeyFn>
+__device__ uint32_t block_coarse_select(KeyFn keyfn, int n, int kk, int* hist, int* aux) {
+    uint32_t prefix = 0;
+    int remaining = kk;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = threadIdx.x; i < CS_BINS; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int base = threadIdx.x; base < n; base += 8 * 256) {
+            uint32_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                key[u] = i < n ? keyfn(i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                if (i >= n) continue;
+                if (pass == 0) atomicAdd(&hist[key[u] >> 20], 1);
+                else if ((key[u] >> 20) == (prefix >> 20)) atomicAdd(&hist[(key[u] >> 8) & 4095], 1);
+            }
+        }
+        __syncthreads();
+        coarse_find_bin(hist, remaining, aux);
+        remaining -= aux[1];
+        prefix |= (uint32_t)aux[0] << (pass == 0 ? 20 : 8);
+        __syncthreads();
+    }
+    return prefix;
+}
+// float value of a truncated key; a truncated -inf key decodes to NaN: map it back
+__device__ __forceinline__ float coarse_value(uint32_t key) {
+    const float v = fkey_inv(key);
+    return v == v ? v : -INFINITY;
+}
+
 // true when the block's query is a padding row of its tile or an all-zero vector: such a query
 // must never emit (every row ties at 0 and would flood the tile's candidate list); a real zero
 // query therefore ends up uncertified and is answered by the exhaustive path.
@@ -409,8 +491,8 @@ __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ samp
                                                   const float* __restrict__ queries, int n_queries,
                                                   int dim, float* __restrict__ tau,
                                                   float* __restrict__ qerr) {
-    __shared__ int hist[256];
-    __shared__ int bc[4];
+    __shared__ int hist[CS_BINS];
+    __shared__ int aux[8];
     __shared__ int flag;
     __shared__ double red[2][256];
     const int q = blockIdx.x;
@@ -448,10 +530,9 @@ __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ samp
         return;
     }
     const float* s = sample_scores + (int64_t)q * sample_ld;
-    int greater;
-    uint32_t key = block_radix_select([&](int i) { return fkey(s[i]); }, n_sample, kk, hist, bc,
-                                      &greater);
-    if (threadIdx.x == 0) tau[q] = fkey_inv(key);
+    // a lower bound of the kk-th sample score is as good a threshold as the score itself
+    const uint32_t key = block_coarse_select([&](int i) { return fkey(s[i]); }, n_sample, kk, hist, aux);
+    if (threadIdx.x == 0) tau[q] = coarse_value(key);
 }
 
 // sequential float64 accumulation of float32 products: the oracle's contract
@@ -469,26 +550,50 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
     return s;
 }
 
-// K4: shortlist, float64 rescoring, ordering, certificate.  One block per query.
+// K4: shortlist, float64 rescoring, ordering, certificate.  One block (4 waves) per query.
+//
+//  band    the candidates that can still reach the top-k: with a_k the k-th largest scan score,
+//          k rows have true cosine >= a_k/||q|| - eps, so a row whose scan score is below
+//          a_k - 2*eps*||q|| cannot beat them.  a_k is replaced by the two-pass lower bound of
+//          block_coarse_select (a slightly wider band, never a narrower one); the first 16
+//          candidates per thread stay in registers across the passes.
+//  rescore float64 SEQUENTIAL sums (the oracle's contract), one lane per row, rows dealt
+//          round-robin to the 4 waves.  Each wave stages its rows through its own LDS tile, 32
+//          dims at a time, with coalesced loads (8 lanes per 128-byte line) and the next chunk
+//          already in flight in registers -- no block barrier inside the loop, the waves run
+//          free.  Lane 63 of wave 3 accumulates ||q||^2 in the same instruction stream.
+//  order   rank sort of the <= 256 rescored rows under (score desc, id asc).
 constexpr int SEL_THREADS = 256;
-__global__ __launch_bounds__(SEL_THREADS) void select_rescore(
+constexpr int RS_ROWS = 32;        // rows per wave per batch
+constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
+constexpr int SEL_REG = 16;        // candidates per thread kept in registers
+static size_t select_lds_bytes(int dim) {
+    const size_t stage = sizeof(float4) * 4 * RS_ROWS * RS_STRIDE, hist = sizeof(int) * CS_BINS;
+    return sizeof(float) * dim + (stage > hist ? stage : hist);
+}
+__global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
     const float* __restrict__ queries, const float* __restrict__ tau,
     const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
     const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
-    double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores, int64_t* __restrict__ out_ids,
-    int32_t* __restrict__ out_counts, uint32_t* __restrict__ out_flags) {
-    extern __shared__ float lds_qv[];  // [dim] query
-    __shared__ int hist[256];
+    double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores,
+    int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts,
+    uint32_t* __restrict__ out_flags) {
+    extern __shared__ float4 lds_sel[];  // [dim/4] query | hist (band) / 4 wave stage tiles (rescore)
+    __shared__ int aux[8];
     __shared__ int bc[4];
-    __shared__ double s_s[THR_DENSE_MAX_K];
-    __shared__ int64_t s_id[THR_DENSE_MAX_K];
+    __shared__ double s_s[THR_DENSE_MAX_K], o_s[THR_DENSE_MAX_K];
+    __shared__ int64_t s_id[THR_DENSE_MAX_K], o_id[THR_DENSE_MAX_K];
     __shared__ int n_sel;
-    __shared__ double s_qn;
+    __shared__ double s_qn, wsum[4];
+    float* lds_qv = reinterpret_cast<float*>(lds_sel);
+    int* hist = reinterpret_cast<int*>(lds_sel + dim / 4);
+    float4* stage_all = lds_sel + dim / 4;
 
     const int q = blockIdx.x;
-    // scan error bound relative to ||q||*||d||: fp32 accumulation, plus -- for the float16
-    // shortlist copy -- row and query quantisation: ea*(1+eq) + eq
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // scan error bound relative to ||q||*||d||: fp32 accumulation, plus -- for the f16 matrix
+    // core scans -- row and query quantisation: ea*(1+eq) + eq
     const double eq = qerr ? (double)qerr[q] : 0.0;
     const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
     const Cand* c = cand + (int64_t)q * CAND_CAP;
@@ -496,61 +601,94 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
     const bool overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
     const int n = overflow ? CAND_CAP : cnt;
 
-    for (int i = threadIdx.x; i < dim; i += SEL_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
+    // candidates this thread keeps in registers (loads in flight while the query is staged)
+    Cand mine[SEL_REG];
+#pragma unroll
+    for (int u = 0; u < SEL_REG; ++u) {
+        const int i = threadIdx.x + u * SEL_THREADS;
+        mine[u] = i < n ? c[i] : Cand{-INFINITY, 0u};
+    }
+    for (int i = threadIdx.x; i < dim / 4; i += SEL_THREADS)
+        lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
     for (int i = threadIdx.x; i < THR_DENSE_MAX_K; i += SEL_THREADS) {
-        s_s[i] = -INFINITY;
-        s_id[i] = INT64_MAX;
+        s_s[i] = o_s[i] = -INFINITY;
+        s_id[i] = o_id[i] = INT64_MAX;
     }
     if (threadIdx.x == 0) n_sel = 0;
     __syncthreads();
 
-    // ||q|| upper bound (parallel float64 sum, inflated) -- only used to size the band below
-    __shared__ double red[SEL_THREADS];
+    // ||q|| upper bound (parallel float64 sum, inflated) -- only used to size the band
     {
         double part = 0.0;
         for (int i = threadIdx.x; i < dim; i += SEL_THREADS) part += (double)lds_qv[i] * (double)lds_qv[i];
-        red[threadIdx.x] = part;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+        if (lane == 0) wsum[wave] = part;
         __syncthreads();
-        for (int o = SEL_THREADS / 2; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
     }
-    const double qn_hi = sqrt(red[0]) * (1.0 + 1e-6);
+    const double qn_hi = sqrt(wsum[0] + wsum[1] + wsum[2] + wsum[3]) * (1.0 + 1e-6);
 
-    // Shortlist = the BAND of candidates that can still reach the top-k.  With a_k the k-th
-    // largest scan score, k rows have true cosine >= a_k/||q|| - eps, so a row whose scan score
-    // is below a_k - 2*eps*||q|| cannot beat them; only the band [a_k - 2.5*eps*||q||, inf) is
-    // rescored (typically k plus a handful of rows instead of k').  Fallbacks: everything when
-    // the list is short; the kprime best when the band does not fit the block.
+    auto key_of = [&](int i) -> uint32_t {  // candidate i's key: registers first, then memory
+        return fkey(c[i].score);
+    };
     float floor32 = tau[q];
     bool band_done = false;
-    if (n > k && n > 0) {
-        int greater;
-        uint32_t kkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, k, hist, bc,
-                                           &greater);
-        const float band = (float)((double)fkey_inv(kkey) - 2.5 * eps * qn_hi);
-        const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
-        __shared__ int n_band;
-        if (threadIdx.x == 0) n_band = 0;
-        __syncthreads();
-        int mine = 0;
-        for (int i = threadIdx.x; i < n; i += SEL_THREADS) mine += c[i].score >= band_lo ? 1 : 0;
-        if (mine) atomicAdd(&n_band, mine);
-        __syncthreads();
-        if (n_band <= THR_DENSE_MAX_K && band_lo > -INFINITY) {
-            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
-                if (c[i].score >= band_lo) {
-                    int p = atomicAdd(&n_sel, 1);
-                    s_id[p] = c[i].doc;
+    if (n > k) {
+        // lower bound of the k-th largest scan score, two 12-bit passes
+        uint32_t prefix = 0;
+        int remaining = k;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = threadIdx.x; i < CS_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < SEL_REG; ++u) {
+                const uint32_t key = fkey(mine[u].score);
+                if (threadIdx.x + u * SEL_THREADS < n) {
+                    if (pass == 0) atomicAdd(&hist[key >> 20], 1);
+                    else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
                 }
-            // rows outside the band: uncollected ones are below tau, collected ones below band_lo
-            floor32 = fmaxf(floor32, band_lo);
-            band_done = true;
+            }
+            for (int i = threadIdx.x + SEL_REG * SEL_THREADS; i < n; i += SEL_THREADS) {
+                const uint32_t key = key_of(i);
+                if (pass == 0) atomicAdd(&hist[key >> 20], 1);
+                else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
+            }
+            __syncthreads();
+            coarse_find_bin(hist, remaining, aux);
+            remaining -= aux[1];
+            prefix |= (uint32_t)aux[0] << (pass == 0 ? 20 : 8);
+            __syncthreads();
         }
-        __syncthreads();
+        const float a_k = coarse_value(prefix);
+        const float band = (float)((double)a_k - 2.5 * eps * qn_hi);
+        const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
+        if (band_lo > -INFINITY) {
+            // count and collect in one sweep; past THR_DENSE_MAX_K rows only the count matters
+#pragma unroll
+            for (int u = 0; u < SEL_REG; ++u)
+                if (threadIdx.x + u * SEL_THREADS < n && mine[u].score >= band_lo) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    if (p < THR_DENSE_MAX_K) s_id[p] = mine[u].doc;
+                }
+            for (int i = threadIdx.x + SEL_REG * SEL_THREADS; i < n; i += SEL_THREADS)
+                if (c[i].score >= band_lo) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    if (p < THR_DENSE_MAX_K) s_id[p] = c[i].doc;
+                }
+            __syncthreads();
+            if (n_sel <= THR_DENSE_MAX_K) {
+                // rows outside the band: uncollected ones are below tau, collected ones below band_lo
+                floor32 = fmaxf(floor32, band_lo);
+                band_done = true;
+            } else {
+                __syncthreads();
+                if (threadIdx.x == 0) n_sel = 0;
+                __syncthreads();
+            }
+        }
     }
     if (!band_done) {
+        // the band does not fit the block (or the list is short): the kprime best, exactly
         if (n > kprime) {
             int greater;
             uint32_t tkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, kprime,
@@ -574,67 +712,89 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
             if (threadIdx.x == 0) n_sel = n;
         }
     }
-    __syncthreads();
+    __syncthreads();  // also: every wave is done with hist before the stage tiles reuse it
     const int ns = n_sel;
 
-    // float64 rescoring, one thread per shortlisted row (the contract is a SEQUENTIAL float64
-    // sum, so a row cannot be split over lanes).  Rows are staged through LDS 32 dims at a
-    // time with coalesced loads (8 lanes per 128-B line): a thread walking its own 3 KiB row
-    // straight from HBM would wait one memory round trip per 16 bytes.
-    constexpr int RS_STRIDE = 9;  // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
-    float4* rstage = reinterpret_cast<float4*>(lds_qv + dim);
-    const float4* docs4 = reinterpret_cast<const float4*>(docs);
-    double dot = 0.0, qq = 0.0;
-    const int64_t row = threadIdx.x < ns ? s_id[threadIdx.x] : -1;
-    for (int d0 = 0; d0 < dim; d0 += 32) {
-        float4 tmp[8];
+    // ---- float64 rescoring ----
+    // (native vectors, not HIP's float4 class: see dense_scan_mfma2 -- a float4 array that is
+    // copied into LDS is demoted to scratch memory)
+    f32x4* stage = reinterpret_cast<f32x4*>(stage_all) + wave * (RS_ROWS * RS_STRIDE);
+    const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
+    const f32x4* qv4 = reinterpret_cast<const f32x4*>(lds_sel);
+    const int lrow = lane >> 3, lch = lane & 7;
+    const bool q_lane = wave == 3 && lane == 63;  // accumulates ||q||^2 instead of a row
+    const int cpr = dim / 4, nchunk = dim / 32;
+    double qq = 0.0;
+    for (int b0 = 0; b0 < ns || (b0 == 0 && q_lane); b0 += 4 * RS_ROWS) {
+        // shortlist slot of (wave, staged row r) is b0 + wave + 4 r; loader rows lrow + 8 u
+        int64_t off[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int it = u * SEL_THREADS + threadIdx.x;
-            const int rs = it >> 3, ch = it & 7;
-            tmp[u] = rs < ns ? docs4[(s_id[rs] * dim + d0) / 4 + ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) {
+            int j = b0 + wave + 4 * (lrow + 8 * u);
+            j = j < ns ? j : (ns > 0 ? ns - 1 : 0);
+            off[u] = (ns > 0 ? s_id[j] : 0) * cpr + lch;
         }
+        const int jm = b0 + wave + 4 * lane;  // this lane's own row (lanes 0..31)
+        const bool has_row = lane < RS_ROWS && jm < ns;
+        f32x4 nxt[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int it = u * SEL_THREADS + threadIdx.x;
-            rstage[(it >> 3) * RS_STRIDE + (it & 7)] = tmp[u];
-        }
-        __syncthreads();
-        if (threadIdx.x < ns) {
+        for (int u = 0; u < 4; ++u) nxt[u] = docs4[off[u]];
+        double dot = 0.0;
+#pragma unroll 1
+        for (int ck = 0; ck < nchunk; ++ck) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[u];
+            const int cn = ck + 1 < nchunk ? ck + 1 : ck;  // the last trip re-requests its own chunk
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = docs4[off[u] + 8 * cn];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const f32x4* src = q_lane ? qv4 + 8 * ck : stage + (lane & (RS_ROWS - 1)) * RS_STRIDE;
+            const f32x4* qv = qv4 + 8 * ck;
+            double acc = q_lane ? qq : dot;
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch) {
-                const float4 x = rstage[threadIdx.x * RS_STRIDE + ch];
-                const float* qv = lds_qv + d0 + 4 * ch;
-                dot = __dadd_rn(dot, __dmul_rn((double)x.x, (double)qv[0]));
-                dot = __dadd_rn(dot, __dmul_rn((double)x.y, (double)qv[1]));
-                dot = __dadd_rn(dot, __dmul_rn((double)x.z, (double)qv[2]));
-                dot = __dadd_rn(dot, __dmul_rn((double)x.w, (double)qv[3]));
+                const f32x4 x = src[ch], y = qv[ch];
+                acc = __dadd_rn(acc, __dmul_rn((double)x.x, (double)y.x));
+                acc = __dadd_rn(acc, __dmul_rn((double)x.y, (double)y.y));
+                acc = __dadd_rn(acc, __dmul_rn((double)x.z, (double)y.z));
+                acc = __dadd_rn(acc, __dmul_rn((double)x.w, (double)y.w));
             }
+            if (q_lane) qq = acc; else dot = acc;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (threadIdx.x == SEL_THREADS - 1)  // ||q||^2, same sequential order as seq_dot_f64
-            for (int i = d0; i < d0 + 32; ++i)
-                qq = __dadd_rn(qq, __dmul_rn((double)lds_qv[i], (double)lds_qv[i]));
-        __syncthreads();
+        if (q_lane && b0 == 0) s_qn = __dsqrt_rn(qq);
+        if (has_row) s_s[jm] = dot;  // the raw dot product for now
     }
-    if (threadIdx.x == SEL_THREADS - 1) s_qn = __dsqrt_rn(qq);
     __syncthreads();
     if (threadIdx.x < ns) {
-        const double qn = s_qn, dn = dnorm[row];
+        const int64_t row = s_id[threadIdx.x];
+        const double qn = s_qn, dn = dnorm[row], dot = s_s[threadIdx.x];
         double sim = -INFINITY;
         if (dn > 0.0) sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
         s_s[threadIdx.x] = sim;
         s_id[threadIdx.x] = sim == -INFINITY ? INT64_MAX : row + id_base;
     }
     __syncthreads();
-    bitonic_sort_desc<THR_DENSE_MAX_K>(s_s, s_id);
+    // rank sort: ids are distinct, so (score desc, id asc) is a strict order on the valid rows;
+    // rows without an embedding all carry (-inf, INT64_MAX), which is what o_s/o_id hold already
+    if (threadIdx.x < ns && s_id[threadIdx.x] != INT64_MAX) {
+        const double ms = s_s[threadIdx.x];
+        const int64_t mi = s_id[threadIdx.x];
+        int rank = 0;
+        for (int i = 0; i < ns; ++i) rank += better(s_s[i], s_id[i], ms, mi) ? 1 : 0;
+        o_s[rank] = ms;
+        o_id[rank] = mi;
+    }
+    __syncthreads();
 
     // results + certificate
-    int valid = 0;
-    for (int i = 0; i < k; ++i) valid += (s_s[i] > -INFINITY) ? 1 : 0;  // k <= 256, uniform
+    const int valid = __syncthreads_count(threadIdx.x < k && o_s[threadIdx.x] > -INFINITY);
     for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
-        bool ok = s_s[i] > -INFINITY;
-        out_scores[(int64_t)q * k + i] = ok ? s_s[i] : -INFINITY;
-        out_ids[(int64_t)q * k + i] = ok ? s_id[i] : -1;
+        const bool ok = o_s[i] > -INFINITY;
+        out_scores[(int64_t)q * k + i] = ok ? o_s[i] : -INFINITY;
+        out_ids[(int64_t)q * k + i] = ok ? o_id[i] : -1;
     }
     if (threadIdx.x == 0) {
         uint32_t flag = overflow ? THR_FLAG_OVERFLOW : 0u;
@@ -646,9 +806,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_rescore(
         } else if (valid < k) {
             cert = false;
         } else {
-            // rows outside the shortlist have fp32 score <= floor32, hence true
+            // rows outside the shortlist have scan score <= floor32, hence true
             // cosine <= floor32/||q|| + eps; the k-th best must clear that strictly.
-            cert = s_qn > 0.0 && (s_s[k - 1] - (double)floor32 / s_qn) > eps;
+            cert = s_qn > 0.0 && (o_s[k - 1] - (double)floor32 / s_qn) > eps;
         }
         out_flags[q] = flag | (cert ? THR_FLAG_CERTIFIED : 0u);
         out_counts[q] = valid;
@@ -1120,8 +1280,7 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     if ((rc = launch_status())) return rc;
     const double u = 5.9604644775390625e-08;
     const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
-    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS),
-                       sizeof(float) * dim + sizeof(float4) * SEL_THREADS * 9, st,
+    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), select_lds_bytes(dim), st,
                        docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
                        p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores, out_ids,
                        out_counts, out_flags);

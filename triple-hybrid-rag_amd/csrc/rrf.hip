@@ -18,12 +18,6 @@ constexpr int RRF_THREADS = 128;
 constexpr int RRF_MAXC = THR_RRF_MAX_PER_CHANNEL;  // per channel
 constexpr int RRF_SLOTS = 512;                      // >= 3 * RRF_MAXC, power of two
 
-// number of leading non-negative ids
-__device__ __forceinline__ int list_len(const int64_t* l, int n) {
-    int len = 0;
-    while (len < n && l[len] >= 0) ++len;
-    return len;
-}
 // last 1-based position of id in l[0..n), 0 if absent
 __device__ __forceinline__ int last_rank(const int64_t* l, int n, int64_t id) {
     int r = 0;
@@ -42,87 +36,88 @@ __global__ __launch_bounds__(RRF_THREADS) void rrf_fuse_kernel(
     const int64_t* __restrict__ gra, int n_gra, double w_lex, double w_sem, double w_gra, int rrf_k,
     int top_k, int64_t* __restrict__ out_ids, double* __restrict__ out_scores,
     int32_t* __restrict__ out_ranks, int32_t* __restrict__ out_counts) {
+    // one thread per list position: RRF_THREADS == RRF_MAXC
+    static_assert(RRF_THREADS == RRF_MAXC && RRF_THREADS == 2 * WAVE, "one thread per position");
     __shared__ int64_t L[3][RRF_MAXC];
     __shared__ int len[3];
-    __shared__ int is_new[3][RRF_MAXC];
+    __shared__ int wave_new[3][2];
     __shared__ double s_s[RRF_SLOTS];
-    __shared__ int64_t s_pos[RRF_SLOTS];   // sighting position (sort tie-break), then payload index
     __shared__ int64_t c_id[RRF_SLOTS];
     __shared__ int c_rank[RRF_SLOTS][3];
-    __shared__ int n_cand;
+    __shared__ int order[RRF_SLOTS];  // sorted position -> sighting position
 
-    const int q = blockIdx.x;
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t* src[3] = {lex, sem, gra};
     const int width[3] = {lex ? n_lex : 0, sem ? n_sem : 0, gra ? n_gra : 0};
-    for (int ch = 0; ch < 3; ++ch)
-        for (int i = threadIdx.x; i < RRF_MAXC; i += RRF_THREADS)
-            L[ch][i] = (i < width[ch]) ? src[ch][(int64_t)q * width[ch] + i] : -1;
-    for (int i = threadIdx.x; i < RRF_SLOTS; i += RRF_THREADS) {
-        s_s[i] = -INFINITY;
-        s_pos[i] = INT64_MAX;
+    if (t < 3) len[t] = width[t];
+    __syncthreads();
+    // lists end at the first negative id
+    for (int ch = 0; ch < 3; ++ch) {
+        const int64_t id = t < width[ch] ? src[ch][(int64_t)q * width[ch] + t] : -1;
+        L[ch][t] = id;
+        if (t < width[ch] && id < 0) atomicMin(&len[ch], t);
     }
     __syncthreads();
-    if (threadIdx.x < 3) len[threadIdx.x] = list_len(L[threadIdx.x], width[threadIdx.x]);
-    __syncthreads();
 
-    // first sighting flags, channel by channel
-    for (int ch = 0; ch < 3; ++ch)
-        for (int i = threadIdx.x; i < RRF_MAXC; i += RRF_THREADS) {
-            bool nw = false;
-            if (i < len[ch]) {
-                const int64_t id = L[ch][i];
-                nw = !seen_before(L[ch], i, id);
-                for (int e = 0; e < ch && nw; ++e)
-                    if (last_rank(L[e], len[e], id)) nw = false;
-            }
-            is_new[ch][i] = nw ? 1 : 0;
+    // first sighting flags, channel by channel, and their running count = sighting position
+    bool nw[3];
+    int within[3];
+    for (int ch = 0; ch < 3; ++ch) {
+        nw[ch] = false;
+        if (t < len[ch]) {
+            const int64_t id = L[ch][t];
+            nw[ch] = !seen_before(L[ch], t, id);
+            for (int e = 0; e < ch && nw[ch]; ++e)
+                if (last_rank(L[e], len[e], id)) nw[ch] = false;
         }
-    __syncthreads();
-
-    // sighting position = number of new entries before (channel, i); score; stage for the sort
-    for (int ch = 0; ch < 3; ++ch)
-        for (int i = threadIdx.x; i < len[ch]; i += RRF_THREADS) {
-            if (!is_new[ch][i]) continue;
-            int pos = 0;
-            for (int e = 0; e < ch; ++e)
-                for (int j = 0; j < len[e]; ++j) pos += is_new[e][j];
-            for (int j = 0; j < i; ++j) pos += is_new[ch][j];
-            const int64_t id = L[ch][i];
-            const int lr = last_rank(L[0], len[0], id);
-            const int sr = last_rank(L[1], len[1], id);
-            const int gr = last_rank(L[2], len[2], id);
-            double score = 0.0;
-            if (lr) score = __dadd_rn(score, __ddiv_rn(w_lex, (double)(rrf_k + lr)));
-            if (sr) score = __dadd_rn(score, __ddiv_rn(w_sem, (double)(rrf_k + sr)));
-            if (gr) score = __dadd_rn(score, __ddiv_rn(w_gra, (double)(rrf_k + gr)));
-            c_id[pos] = id;
-            c_rank[pos][0] = lr;
-            c_rank[pos][1] = sr;
-            c_rank[pos][2] = gr;
-            s_s[pos] = score;
-            s_pos[pos] = pos;
-        }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int ch = 0; ch < 3; ++ch)
-            for (int j = 0; j < len[ch]; ++j) n += is_new[ch][j];
-        n_cand = n;
+        const uint64_t m = __ballot(nw[ch]);
+        within[ch] = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_new[ch][wave] = __popcll(m);
     }
     __syncthreads();
-    // (score desc, sighting position asc) is exactly Python's stable descending sort
-    bitonic_sort_desc<RRF_SLOTS>(s_s, s_pos);
-    const int n = n_cand;
-    for (int i = threadIdx.x; i < top_k; i += RRF_THREADS) {
+    int base = 0, n = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        const int here = base + (wave ? wave_new[ch][0] : 0) + within[ch];
+        base += wave_new[ch][0] + wave_new[ch][1];
+        if (!nw[ch]) continue;
+        const int64_t id = L[ch][t];
+        const int lr = last_rank(L[0], len[0], id);
+        const int sr = last_rank(L[1], len[1], id);
+        const int gr = last_rank(L[2], len[2], id);
+        double score = 0.0;
+        if (lr) score = __dadd_rn(score, __ddiv_rn(w_lex, (double)(rrf_k + lr)));
+        if (sr) score = __dadd_rn(score, __ddiv_rn(w_sem, (double)(rrf_k + sr)));
+        if (gr) score = __dadd_rn(score, __ddiv_rn(w_gra, (double)(rrf_k + gr)));
+        c_id[here] = id;
+        c_rank[here][0] = lr;
+        c_rank[here][1] = sr;
+        c_rank[here][2] = gr;
+        s_s[here] = score;
+    }
+    n = base;
+    __syncthreads();
+    // (score desc, sighting position asc) is exactly Python's stable descending sort; positions
+    // are distinct, so each candidate's rank is the number of candidates ahead of it
+    for (int p = t; p < n; p += RRF_THREADS) {
+        const double ms = s_s[p];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double o = s_s[j];
+            rank += (o > ms || (o == ms && j < p)) ? 1 : 0;
+        }
+        order[rank] = p;
+    }
+    __syncthreads();
+    for (int i = t; i < top_k; i += RRF_THREADS) {
         const bool ok = i < n;
-        const int p = ok ? (int)s_pos[i] : 0;
+        const int p = ok ? order[i] : 0;
         out_ids[(int64_t)q * top_k + i] = ok ? c_id[p] : -1;
-        out_scores[(int64_t)q * top_k + i] = ok ? s_s[i] : -INFINITY;
+        out_scores[(int64_t)q * top_k + i] = ok ? s_s[p] : -INFINITY;
         if (out_ranks)
             for (int c = 0; c < 3; ++c)
                 out_ranks[((int64_t)q * top_k + i) * 3 + c] = ok ? c_rank[p][c] : 0;
     }
-    if (threadIdx.x == 0) out_counts[q] = n < top_k ? n : top_k;
+    if (t == 0) out_counts[q] = n < top_k ? n : top_k;
 }
 
 }  // namespace thr

@@ -131,9 +131,10 @@ class GpuIndex:
                                           self.doc_base, ws)
         n_rescued = 0
         if rescue:
-            bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
-            n_rescued = int(bad.numel())
+            # one small reduction + one read-back per batch; the index list only when needed
+            n_rescued = int(flg.numel()) - int((flg & N.THR_FLAG_CERTIFIED).ne(0).sum())
             if n_rescued:
+                bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
                 S2, I2, c2, _ = N.dense_topk_exact(self.docs, self.dnorm,
                                                    queries[bad].contiguous(), k, self.doc_base)
                 S[bad], I[bad], cnt[bad] = S2, I2, c2
