@@ -11,12 +11,15 @@ across the ranks (strong scaling, one process per GPU, RCCL all-gather of the pe
 top-100).  Inputs are resident in HBM before the timed region.
 
 The JSON line also carries
-  roofline      the dense scan kernel (dense_scan<MODE_FILTER>) timed with HIP events on its
-                own stream through thr_dense_scan_probe: algorithmic bytes
-                (tiles * n_docs * dim * 4 per launch) / average launch time vs 8 TB/s
-  cpu_baseline  the CPU oracle's fast path (float32 BLAS shortlist + float64 rescoring,
-                oracle/thr_oracle.py dense_topk_fast) timed on this host's cores on a bounded
-                sample of the same workload (rank 0, N = 1 only)
+  roofline         the dense scan kernel of the timed path, launched alone through
+                   thr_dense_scan_probe[_f16] and timed with HIP events on its own stream:
+                   2*N*D*Q flops per launch / average launch time against the dense MFMA peak of
+                   its input type, the PMC HBM bytes per launch (`traffic`), and SURVEY 8(d)'s
+                   passes*N*D*bytes/t figure against 8 TB/s (`hbm_formula`)
+  other_shortlists the same step with the other shortlist scans (same bits out)
+  cpu_baseline     the CPU oracle's fast path (float32 BLAS shortlist + float64 rescoring,
+                   oracle/thr_oracle.py dense_topk_fast) timed on this host's cores on a bounded
+                   sample of the same workload (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
@@ -32,7 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# MI355X peaks (MI355X_MICROARCH.md): HBM3E spec; dense f16 MFMA; f32-input MFMA (= f32 vector)
+HBM_PEAK_GBPS = 8000.0
+MFMA_F16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def parse():
@@ -45,14 +51,14 @@ def parse():
     ap.add_argument("--queries", type=int, default=1024, help="queries per step (batch)")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=64)
+    ap.add_argument("--cpu-queries", type=int, default=1024)
     ap.add_argument("--probe-reps", type=int, default=5)
-    ap.add_argument("--no-f16-extra", action="store_true",
-                    help="skip the additional float16-shortlist measurement reported next to the "
-                         "default float32-scan one")
-    ap.add_argument("--shortlist", choices=("f32", "f16", "f16-inline"), default="f32",
-                    help="f16: opt-in float16 shortlist copy for the streaming pass (results stay "
-                         "float64-exact; see DESIGN.md 4.1b)")
+    ap.add_argument("--no-extras", "--no-f16-extra", dest="no_extras", action="store_true",
+                    help="skip the measurements of the other shortlist flavours reported next to "
+                         "the primary one")
+    ap.add_argument("--shortlist", choices=("auto", "f16-inline", "f16", "f32"), default="auto",
+                    help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16-inline; "
+                         "results are the same float64-exact bits in every flavour (DESIGN.md 4.1)")
     return ap.parse_args()
 
 
@@ -113,8 +119,36 @@ def main():
             elapsed = float(t.item())
         return res, rescued, elapsed
 
-    def probe_scan(f16):
-        """Average launch time of the streaming scan kernel alone (HIP events on its stream)."""
+    FLAVOURS = ("f16-inline", "f16", "f32")
+    KERNEL = {"f32": f"dense_scan_mfma2<dim={args.dim},MODE_FILTER>",
+              "f16": f"dense_scan_f16<dim={args.dim},MODE_FILTER,F32IN=0>",
+              "f16-inline": f"dense_scan_f16<dim={args.dim},MODE_FILTER,F32IN=1>"}
+
+    def set_flavour(name):
+        """Switch the shortlist scan of the (already resident) index in place."""
+        index.shortlist = name
+        if name == "f32":
+            index.docs16, index.doc_rel_err = None, 0.0
+        else:
+            index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(
+                index.docs, keep_copy=name == "f16")
+
+    def pmc(name):
+        """Counters of the scan kernel from the committed --pmc passes (profiles/): HBM-side
+        bytes per launch (FETCH_SIZE x2 on gfx950) and the MFMA pipe's busy share.  Only
+        valid for the shape they were measured on."""
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
+                pm = json.load(f)
+            e = pm["flavours"][name]
+            if pm["n_docs"] == n_local and pm["dim"] == args.dim and pm["queries"] == args.queries:
+                return e
+        except (OSError, KeyError, ValueError):
+            pass
+        return {}
+
+    def probe_scan(name):
+        """The streaming scan kernel alone: average launch time from HIP events on its stream."""
         stream = torch.cuda.current_stream()
         index.scan_probe(qd)  # warm; same workspace (and tau) as the timed searches
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -124,59 +158,48 @@ def main():
         ev1.record(stream)
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / args.probe_reps
-        if f16:
-            qt, elem, name = (64 if args.dim <= 768 else 32), 2, "dense_scan_f16"
-            if index.docs16 is None:
-                elem, name = 4, "dense_scan_f16<F32IN>"
-        else:
-            qt = 16 if os.environ.get("THR_DENSE_QT") == "16" else 32
-            elem = 4
-            name = "dense_scan" if os.environ.get("THR_DENSE_IMPL", "m")[0] == "v" else "dense_scan_mfma2"
-        tiles = (args.queries + qt - 1) // qt
-        alg = tiles * (hi - lo) * args.dim * elem
-        ach = alg / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": f"{name}<dim={args.dim},MODE_FILTER> ({qt} queries/pass)",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "launch_ms": round(ms, 4),
-                "tile_passes_per_launch": tiles, "algorithmic_bytes_per_launch": alg}, qt, tiles
+        f16 = name != "f32"
+        qt = (64 if args.dim <= 768 else 32) if f16 else 32
+        passes = (args.queries + qt - 1) // qt
+        flops = 2.0 * n_local * args.dim * args.queries
+        peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
+        ach = flops / (ms * 1e-3) / 1e12
+        row_bytes = args.dim * (2 if name == "f16" else 4)
+        alg = passes * n_local * row_bytes
+        hbm = alg / (ms * 1e-3) / 1e9
+        c = pmc(name)
+        return {"bound": "mfma", "kernel": f"{KERNEL[name]} ({qt} queries/pass)",
+                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": c.get("hbm_bytes_per_launch"),
+                "launch_ms": round(ms, 4), "flops_per_launch": flops,
+                "mfma_busy": c.get("mfma_busy"),
+                # SURVEY 8(d)'s dense-scan figure (passes * N * D * bytes / t against 8 TB/s).  The
+                # query tiles of a row slice now share each row through their XCD's L2, so the
+                # bytes that reach HBM are `traffic`, not this product: the figure can exceed 1.
+                "hbm_formula": {"passes": passes, "algorithmic_bytes_per_launch": alg,
+                                "achieved": round(hbm, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round(hbm / HBM_PEAK_GBPS, 4)}}
 
+    n_local = hi - lo
+    primary = index.shortlist
     res, rescued, elapsed = measure()
     qps = args.steps * args.queries / elapsed
+    roofline = probe_scan(primary)
 
-    # ---- roofline of the dominant kernel: HIP events around the scan alone ----
-    n_local = hi - lo
-    f16 = args.shortlist != "f32"
-    roofline, qt, tiles = probe_scan(f16)
-
-    def pmc_traffic(kind, qt_expected, ntiles):
-        """HBM bytes per launch from the committed PMC pass (FETCH_SIZE x2 on gfx950), scaled per
-        tile pass; only valid for the shape it was measured on."""
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
-                pm = json.load(f)
-            if pm["n_docs"] == n_local and pm["dim"] == args.dim and qt_expected:
-                return round(pm[kind]["hbm_bytes_per_tile_pass"] * ntiles)
-        except (OSError, KeyError, ValueError):
-            pass
-        return None
-
-    roofline["traffic"] = pmc_traffic("f16" if f16 else "f32", qt == (64 if f16 else 32), tiles)
-
-    # ---- the opt-in float16 shortlist copy, measured in the same run for comparison ----
-    extra = None
-    if not f16 and not args.no_f16_extra and args.dim in (512, 768, 1024):
-        ids_f32 = res.ids.clone()
-        index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(index.docs)
-        res16, rescued16, elapsed16 = measure()
-        roof16, qt16, tiles16 = probe_scan(True)
-        roof16["traffic"] = pmc_traffic("f16", qt16 == 64, tiles16)
-        extra = {"value": round(args.steps * args.queries / elapsed16, 1), "unit": "queries/s",
-                 "ms_per_step": round(1e3 * elapsed16 / args.steps, 3),
-                 "rescued_queries": rescued16, "roofline": roof16,
-                 "fused_top10_identical_to_f32_scan": bool(torch.equal(res16.ids, ids_f32)),
-                 "note": "float16 copy of the rows for the streaming pass only; scores are the "
-                         "float64 rescoring of float32 rows, certificate covers quantisation"}
-        index.docs16, index.doc_rel_err = None, 0.0
+    # ---- the other shortlist flavours, measured in the same run for comparison ----
+    extras = {}
+    if not args.no_extras and args.dim in (512, 768, 1024):
+        ids0 = res.ids.clone()
+        for name in FLAVOURS:
+            if name == primary:
+                continue
+            set_flavour(name)
+            r2, resc2, el2 = measure()
+            extras[name] = {"value": round(args.steps * args.queries / el2, 1), "unit": "queries/s",
+                            "ms_per_step": round(1e3 * el2 / args.steps, 3),
+                            "rescued_queries": resc2, "roofline": probe_scan(name),
+                            "fused_top10_identical_to_primary": bool(torch.equal(r2.ids, ids0))}
+        set_flavour(primary)
 
     # ---- exactness of what was timed + CPU baseline (rank 0, N = 1) ----
     cpu = None
@@ -206,18 +229,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f16 shortlist scan" if f16 else "f32 scan") + " + f64 rescoring of f32 rows",
+            "dtype": ("f32" if primary == "f32" else "f16") + " MFMA shortlist scan (f32 accumulate) + "
+                     "f64 rescoring of the f32 rows",
             "data": "synthetic",
             "config": {"workload": f"{args.docs}-doc / {args.dim}-d dense-only brute-force cosine "
                                    f"top-{args.top_k} (BASELINE.json configs[1])",
                        "docs": args.docs, "dim": args.dim, "queries_per_step": args.queries,
-                       "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": args.shortlist,
+                       "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": primary,
                        "parallelism": f"doc-shard x{world}" if world > 1 else "single GPU",
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if extra:
-            out["f16_shortlist"] = extra
+        if extras:
+            out["other_shortlists"] = extras
         if check:
             out["parity_check"] = check
         print(json.dumps(out), flush=True)

@@ -588,3 +588,12 @@ def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
                                    [{"chunk_id": f"c{i}"} for i in Il50[0]]], 60)[:10]
         assert [r.chunk_id for r in out] == [e["chunk_id"] for e in exp]
         assert [r.rrf_score for r in out] == [e["rrf_score"] for e in exp]
+
+
+def test_dense_auto_shortlist_choice(T):
+    x, _ = rand_docs(3000, 768, 6)
+    assert T.GpuIndex().set_dense(x).shortlist == "f16-inline"
+    assert T.GpuIndex().set_dense(x[:, :256].copy()).shortlist == "f32"   # no f16 kernel at dim 256
+    x[5, 7] = -2e5
+    idx = T.GpuIndex().set_dense(x)
+    assert idx.shortlist == "f32" and idx.docs16 is None and idx.doc_rel_err == 0.0

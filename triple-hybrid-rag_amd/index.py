@@ -60,27 +60,36 @@ class GpuIndex:
             return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
 
-    SHORTLISTS = ("f32", "f16", "f16-inline")
+    SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
+    F16_DIMS = (512, 768, 1024)
 
-    def set_dense(self, docs, shortlist: str = "f32") -> "GpuIndex":
+    def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
         rescoring of the float32 rows, and the per-query certificate covers the scan's error):
           "f32"        float32 rows on the fp32 matrix cores (32 queries per pass);
           "f16-inline" float32 rows rounded to float16 in registers, f16 matrix cores
                        (64 queries per pass, no extra memory);
-          "f16"        additionally keeps a float16 copy of the rows and streams that."""
+          "f16"        additionally keeps a float16 copy of the rows and streams that;
+          "auto"       "f16-inline" when the dimension has an f16 kernel and every row fits the
+                       float16 range, else "f32"."""
         if shortlist not in self.SHORTLISTS:
             raise ValueError(f"shortlist must be one of {self.SHORTLISTS}")
         self.docs = self._t(docs, torch.float32)
         self.n_docs, self.dim = self.docs.shape
         self.dnorm, self.inv_norm = N.doc_norms(self.docs)
         self.docs16, self.doc_rel_err = (None, 0.0)
-        self.shortlist = shortlist
+        auto = shortlist == "auto"
+        if auto:
+            shortlist = "f16-inline" if self.dim in self.F16_DIMS else "f32"
         if shortlist != "f32":
             self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
                                                                  keep_copy=shortlist == "f16")
             if not np.isfinite(self.doc_rel_err):
-                raise N.NativeError("rows do not fit float16 (|value| >= 65504): use shortlist='f32'")
+                if not auto:
+                    raise N.NativeError("rows do not fit float16 (|value| >= 65504): use "
+                                        "shortlist='f32'")
+                shortlist, self.docs16, self.doc_rel_err = "f32", None, 0.0
+        self.shortlist = shortlist
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
