@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 1
+#define THR_ABI_VERSION 2
 
 typedef void *thr_stream_t;
 
@@ -181,12 +181,16 @@ int thr_maxsim(const uint16_t *qtok /* f16 [nq,q_tokens,tok_dim] */, int n_queri
                int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
                float *out_scores /* [nq,n_cand] */, thr_stream_t stream);
 
-/* Merge step of the multi-GPU path: G per-shard ranked lists -> global top-k
- * under (score desc, id asc).  in_* are [n_queries, n_lists, k_in] as laid out
- * by an all-gather of each rank's [n_queries, k_in] block. */
+/* Merge step of the multi-GPU path: G per-shard ranked lists -> global top-k under
+ * (score desc, id asc).  List l of query q starts at in_*[l * list_stride + q * k_in]
+ * (elements); list_stride = 0 means n_queries * k_in, i.e. the [n_lists, n_queries, k_in]
+ * layout an all-gather of each rank's [n_queries, k_in] block produces -- a larger stride lets
+ * scores and ids be read in place from one gathered [n_lists, 2, n_queries, k_in] tile.
+ * Entries with score -inf or a negative id are padding.  Ids must be distinct across lists
+ * (disjoint shards).  Lists that arrive ranked (the normal case) are merged without a sort. */
 int thr_merge_topk(const double *in_scores, const int64_t *in_ids, int n_queries, int n_lists,
-                   int k_in, int k_out, double *out_scores, int64_t *out_ids, int32_t *out_counts,
-                   thr_stream_t stream);
+                   int k_in, int64_t list_stride, int k_out, double *out_scores, int64_t *out_ids,
+                   int32_t *out_counts, thr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -247,6 +247,7 @@ def test_maxsim_matches_oracle(T):
 
 
 def test_merge_topk(T):
+    import torch
     rng = np.random.default_rng(2)
     G, nq, k = 8, 33, 100
     S = np.sort(rng.standard_normal((G, nq, k)), axis=2)[:, :, ::-1].copy()
@@ -254,11 +255,33 @@ def test_merge_topk(T):
     S[3, :, 60:] = -np.inf
     I[3, :, 60:] = -1
     S[1, 0, :5] = S[0, 0, :5]  # cross-shard ties -> id asc
+    def check(S, I, s, i, k_out=100):
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+        for q in range(S.shape[1]):
+            es, ei = O.topk_desc(S[:, q, :].ravel(), k_out, I[:, q, :].ravel())
+            m = len(es)
+            assert np.array_equal(i[q][:m], ei) and np.array_equal(s[q][:m], es)
+            assert np.all(i[q][m:] == -1) and np.all(np.isneginf(s[q][m:]))
+
     s, i, cnt = T._native.merge_topk(dev(S), dev(I), 100)
-    s, i = s.cpu().numpy(), i.cpu().numpy()
-    for q in range(nq):
-        es, ei = O.topk_desc(S[:, q, :].ravel(), 100, I[:, q, :].ravel())
-        assert np.array_equal(i[q], ei) and np.array_equal(s[q], es)
+    check(S, I, s, i)
+    # read in place from one gathered [G, 2, nq, k] tile (what distributed.gather_topk returns)
+    tile = torch.stack([dev(S).view(torch.int64), dev(I)], dim=1).contiguous()
+    s, i, cnt = T._native.merge_topk(tile[:, 0].view(torch.float64), tile[:, 1], 10)
+    check(S, I, s, i, 10)
+    # a list that is not ranked: the block falls back to sorting everything
+    S2 = S.copy()
+    S2[5, :, :] = S2[5, :, ::-1]
+    s, i, cnt = T._native.merge_topk(dev(S2), dev(I), 100)
+    check(S2, I, s, i)
+    # fewer valid entries than k_out; and more than 1024 candidates per query (general kernel)
+    s, i, cnt = T._native.merge_topk(dev(S[3:4, :, :]), dev(I[3:4, :, :]), 100)
+    check(S[3:4], I[3:4], s, i)
+    assert np.all(cnt.cpu().numpy() == 60)
+    S3 = np.concatenate([S, S + 0.25], axis=0)
+    I3 = np.concatenate([I, I + G * nq * k], axis=0)
+    s, i, cnt = T._native.merge_topk(dev(S3), dev(I3), 100)
+    check(S3, I3, s, i)
 
 
 def test_triple_hybrid_pipeline_fused_top10(T):

@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -60,7 +60,7 @@ _SIGNATURES = {
     "thr_rrf_fuse": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
                             _vp, _vp, _vp, _vp, _vp]),
     "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
-    "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -155,8 +155,10 @@ def dense_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int) ->
 
 
 def _alloc_out(nq: int, k: int, device):
-    return (torch.empty((nq, k), dtype=torch.float64, device=device),
-            torch.empty((nq, k), dtype=torch.int64, device=device),
+    # scores and ids are the two halves of ONE [2, nq, k] 8-byte tile: the multi-GPU exchange
+    # all-gathers that tile as it is (distributed.gather_topk), no packing copy
+    tile = torch.empty((2, nq, k), dtype=torch.int64, device=device)
+    return (tile[0].view(torch.float64), tile[1],
             torch.empty(nq, dtype=torch.int32, device=device),
             torch.empty(nq, dtype=torch.int32, device=device))
 
@@ -369,16 +371,22 @@ def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor) -> torch.
 
 # ------------------------------------------------------------- multi-GPU
 def merge_topk(in_scores: torch.Tensor, in_ids: torch.Tensor, k_out: int):
-    """in_* are [n_lists, n_queries, k_in] (the layout an all-gather of each
-    rank's [n_queries, k_in] block produces)."""
-    ps = _dev(in_scores, torch.float64, "in_scores", 3)
-    pi = _dev(in_ids, torch.int64, "in_ids", 3)
-    if in_scores.shape != in_ids.shape:
+    """in_* are [n_lists, n_queries, k_in] (the layout an all-gather of each rank's
+    [n_queries, k_in] block produces); they may be strided views of one gathered
+    [n_lists, 2, n_queries, k_in] tile (same list stride, contiguous [n_queries, k_in] blocks)."""
+    if in_scores.shape != in_ids.shape or in_scores.dim() != 3:
         raise NativeError("merge: shape mismatch")
+    if in_scores.dtype != torch.float64 or in_ids.dtype != torch.int64 or not in_scores.is_cuda:
+        raise NativeError("merge: in_scores must be float64, in_ids int64, on the GPU")
     nl, nq, kin = in_scores.shape
-    S = torch.empty((nq, k_out), dtype=torch.float64, device=in_scores.device)
-    I = torch.empty((nq, k_out), dtype=torch.int64, device=in_scores.device)
-    cnt = torch.empty(nq, dtype=torch.int32, device=in_scores.device)
-    _check(load().thr_merge_topk(ps, pi, nq, nl, kin, k_out, S.data_ptr(), I.data_ptr(),
-                                 cnt.data_ptr(), _stream()), "thr_merge_topk")
+    for t in (in_scores, in_ids):
+        if t.stride(2) != 1 or t.stride(1) != kin or (nl > 1 and t.stride(0) < nq * kin):
+            raise NativeError("merge: lists must be contiguous [n_queries, k_in] blocks")
+    if nl > 1 and in_scores.stride(0) != in_ids.stride(0):
+        raise NativeError("merge: scores and ids must share the list stride")
+    stride = in_scores.stride(0) if nl > 1 else nq * kin
+    S, I, cnt, _ = _alloc_out(nq, k_out, in_scores.device)
+    _check(load().thr_merge_topk(in_scores.data_ptr(), in_ids.data_ptr(), nq, nl, kin, stride,
+                                 k_out, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), _stream()),
+           "thr_merge_topk")
     return S, I, cnt

@@ -906,6 +906,80 @@ __global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in
     }
 }
 
+// Merge of at most EX_CAP candidates per query held entirely in LDS: the per-shard lists of the
+// multi-GPU path (8 x <= 128).  The lists arrive ranked under (score desc, id asc) with disjoint
+// ids, so an entry's place in the merged order is its own position plus, per other list, the
+// number of entries ahead of it there (one binary search each) -- no sort.  A list that is NOT
+// ranked makes the block fall back to a bitonic sort of everything (same result, slower).
+__global__ __launch_bounds__(256) void merge_ranked_lists(const double* __restrict__ in_s,
+                                                          const int64_t* __restrict__ in_id,
+                                                          int64_t q_stride, int64_t list_stride,
+                                                          int n_lists, int k_in, int k_out,
+                                                          double* __restrict__ out_s,
+                                                          int64_t* __restrict__ out_id,
+                                                          int32_t* __restrict__ out_counts) {
+    __shared__ double b_s[EX_CAP];
+    __shared__ int64_t b_id[EX_CAP];
+    __shared__ int unsorted, n_valid;
+    const int q = blockIdx.x;
+    const int total = n_lists * k_in;
+    if (threadIdx.x == 0) unsorted = 0, n_valid = 0;
+    for (int i = threadIdx.x; i < EX_CAP; i += blockDim.x) {
+        double sc = -INFINITY;
+        int64_t id = INT64_MAX;
+        if (i < total) {
+            const int64_t o = (int64_t)q * q_stride + (int64_t)(i / k_in) * list_stride + (i % k_in);
+            sc = in_s[o];
+            id = in_id[o];
+            if (!(sc > -INFINITY) || id < 0) sc = -INFINITY, id = INT64_MAX;
+        }
+        b_s[i] = sc;
+        b_id[i] = id;
+    }
+    for (int i = threadIdx.x; i < k_out; i += blockDim.x) {
+        out_s[(int64_t)q * k_out + i] = -INFINITY;
+        out_id[(int64_t)q * k_out + i] = -1;
+    }
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        mine += b_id[i] != INT64_MAX ? 1 : 0;
+        if (i % k_in + 1 < k_in && better(b_s[i + 1], b_id[i + 1], b_s[i], b_id[i])) unsorted = 1;
+    }
+    if (mine) atomicAdd(&n_valid, mine);
+    __syncthreads();
+    if (!unsorted) {
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const double ms = b_s[i];
+            const int64_t mi = b_id[i];
+            if (mi == INT64_MAX) continue;
+            const int a = i / k_in;
+            int rank = i % k_in;
+            for (int b = 0; b < n_lists && rank < k_out; ++b) {
+                if (b == a) continue;
+                int lo = 0, hi = k_in;  // first position of list b that is not ahead of (ms, mi)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (better(b_s[b * k_in + mid], b_id[b * k_in + mid], ms, mi)) lo = mid + 1;
+                    else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < k_out) {
+                out_s[(int64_t)q * k_out + rank] = ms;
+                out_id[(int64_t)q * k_out + rank] = mi;
+            }
+        }
+    } else {
+        bitonic_sort_desc<EX_CAP>(b_s, b_id);
+        for (int i = threadIdx.x; i < k_out && i < n_valid; i += blockDim.x) {
+            out_s[(int64_t)q * k_out + i] = b_s[i];
+            out_id[(int64_t)q * k_out + i] = b_id[i];
+        }
+    }
+    if (threadIdx.x == 0 && out_counts) out_counts[q] = n_valid < k_out ? n_valid : k_out;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1434,15 +1508,23 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
 }
 
 extern "C" int thr_merge_topk(const double* in_scores, const int64_t* in_ids, int n_queries,
-                              int n_lists, int k_in, int k_out, double* out_scores,
-                              int64_t* out_ids, int32_t* out_counts, thr_stream_t stream) {
+                              int n_lists, int k_in, int64_t list_stride, int k_out,
+                              double* out_scores, int64_t* out_ids, int32_t* out_counts,
+                              thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!in_scores || !in_ids || !out_scores || !out_ids, THR_ERR_INVALID);
     THR_RETURN_IF(n_queries <= 0 || n_lists <= 0 || k_in <= 0 || k_out <= 0 || k_out > EX_CAP / 2,
                   THR_ERR_INVALID);
-    // all-gather layout: [n_lists, n_queries, k_in]
+    if (list_stride == 0) list_stride = (int64_t)n_queries * k_in;  // [n_lists, n_queries, k_in]
+    THR_RETURN_IF(list_stride < (int64_t)n_queries * k_in, THR_ERR_INVALID);
+    if ((int64_t)n_lists * k_in <= EX_CAP) {
+        hipLaunchKernelGGL(merge_ranked_lists, dim3(n_queries), dim3(256), 0, (hipStream_t)stream,
+                           in_scores, in_ids, (int64_t)k_in, list_stride, n_lists, k_in, k_out,
+                           out_scores, out_ids, out_counts);
+        return launch_status();
+    }
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, (hipStream_t)stream, in_scores,
-                       in_ids, (int64_t)k_in, (int64_t)n_queries * k_in, n_lists, k_in, k_out,
+                       in_ids, (int64_t)k_in, list_stride, n_lists, k_in, k_out,
                        (int64_t)0, 0u, out_scores, out_ids, out_counts, (uint32_t*)nullptr);
     return launch_status();
 }

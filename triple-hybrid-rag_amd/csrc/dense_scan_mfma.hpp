@@ -370,17 +370,28 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
             MF2_STAGE(3, ring0, qb + 16, qn)
         }
 
+        if constexpr (MODE == MODE_ALL) {
+            // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
+            const int qg = qtile * MF_QT + r;
+            float* dst = sample_scores + (int64_t)qg * sample_ld + t * MF_ROWS + 4 * h;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float inv = __shfl(my_inv, row, WAVE);
-            const bool ok = row0 + row < n_docs;
-            const float sc = acc[i] * inv;
-            if constexpr (MODE == MODE_ALL) {
-                const int qg = qtile * MF_QT + r;
-                sample_scores[(int64_t)qg * sample_ld + t * MF_ROWS + row] =
-                    (ok && inv > 0.f) ? sc : -INFINITY;
-            } else {
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = j + 8 * g + 4 * h;
+                    const float inv = __shfl(my_inv, row, WAVE);
+                    v[j] = (row0 + row < n_docs && inv > 0.f) ? acc[4 * g + j] * inv : -INFINITY;
+                }
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float inv = __shfl(my_inv, row, WAVE);
+                const bool ok = row0 + row < n_docs;
+                const float sc = acc[i] * inv;
                 const bool pass = ok && inv > 0.f && sc >= my_tau;
                 const uint64_t m = __ballot(pass);
                 if (m) {

@@ -28,14 +28,27 @@ def shard_range(n_docs: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_docs, lo + per)
 
 
+def _as_tile(scores: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """The [2, nq, k] int64 tile whose halves ``scores`` (as bit patterns) and ``ids`` are.  The
+    kernels' outputs already are the two halves of one allocation (_native._alloc_out): then
+    this is a view, otherwise one packing copy."""
+    nq, k = ids.shape
+    if (scores.is_contiguous() and ids.is_contiguous() and scores.dtype == torch.float64
+            and scores.untyped_storage().data_ptr() == ids.untyped_storage().data_ptr()
+            and ids.data_ptr() - scores.data_ptr() == nq * k * 8):
+        return torch.as_strided(scores.view(torch.int64), (2, nq, k), (nq * k, k, 1))
+    return torch.stack([scores.contiguous().view(torch.int64), ids.contiguous()])
+
+
 def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather each rank's [nq, k] (scores f64, ids i64) -> [world, nq, k] on every rank.
     ONE collective per channel: the float64 scores travel as their int64 bit patterns next to
     the ids in a single [2, nq, k] int64 tile (the exchange is latency-bound, not
-    bandwidth-bound).  Backend-agnostic (RCCL on GPUs; gloo in the CPU tests)."""
+    bandwidth-bound).  The results are strided views of the gathered [world, 2, nq, k] tile,
+    which thr_merge_topk reads in place.  Backend-agnostic (RCCL on GPUs; gloo in the CPU tests)."""
     world = dist.get_world_size(group)
-    tile = torch.stack([scores.contiguous().view(torch.int64), ids.contiguous()])  # [2, nq, k]
+    tile = _as_tile(scores, ids)
     out = torch.empty((world,) + tuple(tile.shape), dtype=torch.int64, device=tile.device)
     if dist.get_backend(group) == "gloo":
         # CPU rendezvous (tests / rehearsals): stage through host memory if the tiles are on a GPU
@@ -44,7 +57,7 @@ def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
         out = torch.stack(host).to(tile.device)
     else:
         dist.all_gather_into_tensor(out, tile, group=group)
-    return out[:, 0].contiguous().view(torch.float64), out[:, 1].contiguous()
+    return out[:, 0].view(torch.float64), out[:, 1]
 
 
 class ShardedIndex:

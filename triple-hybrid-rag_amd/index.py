@@ -141,7 +141,7 @@ class GpuIndex:
         n_rescued = 0
         if rescue:
             # one small reduction + one read-back per batch; the index list only when needed
-            n_rescued = int(flg.numel()) - int((flg & N.THR_FLAG_CERTIFIED).ne(0).sum())
+            n_rescued = int(flg.numel()) - int((flg & N.THR_FLAG_CERTIFIED).sum())  # flag bit = 1
             if n_rescued:
                 bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
                 S2, I2, c2, _ = N.dense_topk_exact(self.docs, self.dnorm,
