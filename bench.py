@@ -57,7 +57,7 @@ def parse():
                     help="skip the measurements of the other shortlist flavours reported next to "
                          "the primary one")
     ap.add_argument("--shortlist", choices=("auto", "f16-inline", "f16", "f32"), default="auto",
-                    help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16-inline; "
+                    help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16 copy; "
                          "results are the same float64-exact bits in every flavour (DESIGN.md 4.1)")
     return ap.parse_args()
 

@@ -615,7 +615,14 @@ def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
 
 def test_dense_auto_shortlist_choice(T):
     x, _ = rand_docs(3000, 768, 6)
-    assert T.GpuIndex().set_dense(x).shortlist == "f16-inline"
+    idx = T.GpuIndex().set_dense(x)
+    assert idx.shortlist == "f16" and idx.docs16 is not None
+    T.GpuIndex.AUTO_COPY_FRACTION, keep = 0.0, T.GpuIndex.AUTO_COPY_FRACTION
+    try:
+        idx = T.GpuIndex().set_dense(x)
+        assert idx.shortlist == "f16-inline" and idx.docs16 is None
+    finally:
+        T.GpuIndex.AUTO_COPY_FRACTION = keep
     assert T.GpuIndex().set_dense(x[:, :256].copy()).shortlist == "f32"   # no f16 kernel at dim 256
     x[5, 7] = -2e5
     idx = T.GpuIndex().set_dense(x)

@@ -62,6 +62,7 @@ class GpuIndex:
 
     SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
     F16_DIMS = (512, 768, 1024)
+    AUTO_COPY_FRACTION = 0.10
 
     def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
@@ -70,8 +71,9 @@ class GpuIndex:
           "f16-inline" float32 rows rounded to float16 in registers, f16 matrix cores
                        (64 queries per pass, no extra memory);
           "f16"        additionally keeps a float16 copy of the rows and streams that;
-          "auto"       "f16-inline" when the dimension has an f16 kernel and every row fits the
-                       float16 range, else "f32"."""
+          "auto"       an f16 flavour when the dimension has an f16 kernel and every row fits the
+                       float16 range -- "f16" while the copy is small next to the device's memory
+                       (<= AUTO_COPY_FRACTION of it), "f16-inline" beyond -- else "f32"."""
         if shortlist not in self.SHORTLISTS:
             raise ValueError(f"shortlist must be one of {self.SHORTLISTS}")
         self.docs = self._t(docs, torch.float32)
@@ -80,7 +82,11 @@ class GpuIndex:
         self.docs16, self.doc_rel_err = (None, 0.0)
         auto = shortlist == "auto"
         if auto:
-            shortlist = "f16-inline" if self.dim in self.F16_DIMS else "f32"
+            shortlist = "f32"
+            if self.dim in self.F16_DIMS:
+                total = torch.cuda.get_device_properties(self.device).total_memory
+                copy_bytes = 2 * self.n_docs * self.dim
+                shortlist = "f16" if copy_bytes <= self.AUTO_COPY_FRACTION * total else "f16-inline"
         if shortlist != "f32":
             self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
                                                                  keep_copy=shortlist == "f16")
