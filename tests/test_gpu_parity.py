@@ -184,6 +184,40 @@ def test_graph_matches_oracle(T):
     assert e == len(g.ent_rowptr) - 1
 
 
+def test_graph_capacity_tiers(T):
+    """Queries beyond the first launch's small on-chip capacities (1024 entities / 2048
+    contributions) are redone with the full ones; beyond those the overflow is reported."""
+    rng = np.random.default_rng(9)
+    n_ent, n_chunks = 20000, 50000
+    deg = np.full(n_ent, 2, dtype=np.int64)
+    deg[0], deg[1], deg[2] = 1200, 40, 6000           # hubs: medium, small-but-many-mentions, huge
+    ent_rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    ent_col = rng.integers(3, n_ent, ent_rowptr[-1]).astype(np.int32)
+    ent_col[ent_rowptr[0]:ent_rowptr[1]] = rng.choice(np.arange(3, n_ent), 1200, replace=False)
+    ent_col[ent_rowptr[2]:ent_rowptr[3]] = rng.choice(np.arange(3, n_ent), 6000, replace=False)
+    men = np.full(n_ent, 1, dtype=np.int64)
+    men[1] = 3000                                      # > 2048 contributions from one entity
+    men_rowptr = np.concatenate([[0], np.cumsum(men)]).astype(np.int64)
+    men_chunk = rng.integers(0, n_chunks, men_rowptr[-1]).astype(np.int32)
+    men_conf = rng.uniform(0.5, 1.0, men_rowptr[-1]).astype(np.float32)
+    seeds = np.array([[0, -1, -1], [1, -1, -1], [2, -1, -1], [7, 8, 9]], dtype=np.int32)
+    idx = T.GpuIndex()
+    idx.n_docs = n_chunks
+    idx.set_graph(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf)
+    for hops in (1, 2):
+        S, I, cnt, flg = T._native.graph_topk(idx.graph["ent_rowptr"], idx.graph["ent_col"],
+                                              idx.graph["men_rowptr"], idx.graph["men_chunk"],
+                                              idx.graph["men_conf"], dev(seeds), hops, 50, 0,
+                                              n_chunks)
+        flg = flg.cpu().numpy()
+        Se, Ie = O.graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, seeds, hops,
+                              n_chunks, 50)
+        ok = [q for q in range(4) if not (hops >= 1 and q == 2)]   # query 2: > 4096 entities
+        assert flg[2] & 2 and all(flg[q] & 1 for q in ok)
+        assert_topk_equal(S[ok], I[ok], cnt[ok], [Se[q] for q in ok], [Ie[q] for q in ok],
+                          [len(Se[q]) for q in ok], f"graph tiers hops={hops}")
+
+
 def test_rrf_fuse_matches_reference_python(T, golden):
     rng = np.random.default_rng(11)
     nq = 64

@@ -10,22 +10,26 @@
 // One workgroup per query.  Posting lists are doc-sorted, so a doc's score is
 // assembled by its OWNER posting -- the posting of the first query term that
 // contains the doc -- which binary-searches the later terms' lists.  That
-// gives the fixed summation order with no atomics and no hash table.  When a
-// query's lists fit, they are staged in LDS first (posting-block staging) and
-// the searches run there; longer lists are searched in HBM/L2.
+// gives the fixed summation order with no atomics and no hash table.  The doc
+// ids are staged in LDS (posting-block staging, in doc-range passes that always
+// fit) and the searches run there -- a search in HBM/L2 is a chain of ~13
+// dependent loads per term; term frequencies are read from memory only for the
+// postings that need them.
 // Algorithmic bytes per query: sum_t df_t * (4 doc + 4 tf + 4 doclen) + T * 16.
 #include "thr_common.hpp"
 
 namespace thr {
 
-constexpr int BM_THREADS = 256;
-constexpr int BM_CAP = 1024;       // BlockTopK buffer
-constexpr int BM_STAGE = 4096;     // postings staged in LDS (32 KiB) when the query fits
+constexpr int BM_THREADS = 512;
+constexpr int BM_CAP = 1024;       // BlockTopK buffer (>= k + BM_THREADS)
+constexpr int BM_STAGE = 8192;     // doc ids staged in LDS per doc-range pass (32 KiB)
 
 struct TermRange {
-    int64_t lo;
-    int len;
-    int lds_off;  // offset into the staged arrays
+    int64_t lo;   // first posting of the term
+    int len;      // postings of the term
+    int cur;      // postings already consumed by earlier doc-range passes
+    int sub;      // postings of the current pass: [cur, cur + sub)
+    int lds_off;  // offset of the current pass's doc ids in the staged array
 };
 
 // lower_bound on a doc-sorted posting list; returns index or -1
@@ -38,6 +42,15 @@ __device__ __forceinline__ int find_doc(Ptr docs, int len, int32_t d) {
     }
     return (lo < len && docs[lo] == d) ? lo : -1;
 }
+// number of postings with doc < d
+__device__ __forceinline__ int count_below(const int32_t* docs, int len, int64_t d) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if ((int64_t)docs[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 __device__ __forceinline__ double bm25_contrib(double idf, double tf, double dl, double avgdl,
                                                double k1, double b) {
@@ -46,23 +59,28 @@ __device__ __forceinline__ double bm25_contrib(double idf, double tf, double dl,
     return __dmul_rn(idf, __ddiv_rn(__dmul_rn(tf, __dadd_rn(k1, 1.0)), __dadd_rn(tf, nrm)));
 }
 
+// The query's postings are consumed in DOC-RANGE passes: a pass takes, from every term's list,
+// the postings with doc id in [d_lo, d_hi) -- a contiguous piece of each doc-sorted list -- so
+// that all pieces together fit the LDS stage (d_hi is halved towards d_lo until they do).  A doc's
+// postings all fall into the same pass, so the owner search never leaves LDS, whatever the
+// length of the lists.
 __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
-    const double* __restrict__ idf, double avgdl, double k1, double b, int64_t id_base,
-    const int32_t* __restrict__ query_terms, int max_terms, int k, double* __restrict__ out_s,
-    int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
+    const double* __restrict__ idf, double avgdl, double k1, double b, int64_t n_docs,
+    int64_t id_base, const int32_t* __restrict__ query_terms, int max_terms, int k,
+    double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
     __shared__ TermRange tr[THR_BM25_MAX_TERMS];
     __shared__ double t_idf[THR_BM25_MAX_TERMS];
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
-    __shared__ int n_terms;
+    __shared__ int n_terms, remaining;
+    __shared__ int64_t range_lo, range_hi;
     __shared__ double b_s[BM_CAP];
     __shared__ int64_t b_id[BM_CAP];
     __shared__ int b_cnt;
     __shared__ double th_s;
     __shared__ int64_t th_id;
     __shared__ int32_t st_doc[BM_STAGE];
-    __shared__ int32_t st_tf[BM_STAGE];
 
     const int q = blockIdx.x;
     if (threadIdx.x == 0) {
@@ -73,73 +91,99 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
             int64_t lo = rowptr[term], hi = rowptr[term + 1];
             tr[nt].lo = lo;
             tr[nt].len = (int)(hi - lo);
-            tr[nt].lds_off = total;
+            tr[nt].cur = 0;
             t_idf[nt] = idf[term];
-            t_prefix[nt] = total;
             total += (int)(hi - lo);
             ++nt;
         }
-        t_prefix[nt] = total;
         n_terms = nt;
+        remaining = total;
+        range_lo = 0;
     }
     BlockTopK<BM_CAP> tk;
     tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
     const int nt = n_terms;
-    const int total = t_prefix[nt];
-    const bool staged = total <= BM_STAGE;
-    if (staged) {
+
+    while (remaining > 0) {
+        // ---- choose [range_lo, range_hi): everything left if it fits, else a share of the doc
+        //      space proportional to the stage size, halved until the pieces fit ----
+        if (threadIdx.x == 0) {
+            int64_t span = n_docs - range_lo;
+            if (remaining > BM_STAGE) {
+                span = (int64_t)((double)span * (0.75 * BM_STAGE) / (double)remaining);
+                if (span < 1) span = 1;
+            }
+            range_hi = range_lo + span;
+        }
+        __syncthreads();
+        for (;;) {
+            if (threadIdx.x < nt) {
+                TermRange& r = tr[threadIdx.x];
+                r.sub = range_hi >= n_docs
+                            ? r.len - r.cur
+                            : count_below(post_doc + r.lo + r.cur, r.len - r.cur, range_hi);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int total = 0;
+                for (int t = 0; t < nt; ++t) {
+                    tr[t].lds_off = total;
+                    t_prefix[t] = total;
+                    total += tr[t].sub;
+                }
+                t_prefix[nt] = total;
+                // a single doc holds at most nt postings, so a one-doc range always fits
+                if (total > BM_STAGE && range_hi - range_lo > 1)
+                    range_hi = range_lo + (range_hi - range_lo) / 2;
+                else
+                    range_lo = -1 - range_lo;  // accepted (decoded below)
+            }
+            __syncthreads();
+            if (range_lo < 0) break;
+        }
+        const int total = t_prefix[nt];
         for (int i = threadIdx.x; i < total; i += BM_THREADS) {
             int t = 0;
             while (i >= t_prefix[t + 1]) ++t;
-            int64_t p = tr[t].lo + (i - t_prefix[t]);
-            st_doc[i] = post_doc[p];
-            st_tf[i] = post_tf[p];
+            st_doc[i] = post_doc[tr[t].lo + tr[t].cur + (i - t_prefix[t])];
         }
         __syncthreads();
-    }
 
-    for (int base = 0; base < total; base += BM_THREADS) {
-        const int i = base + threadIdx.x;
-        bool owner = false;
-        double score = 0.0;
-        int32_t d = 0;
-        if (i < total) {
-            int t = 0;
-            while (i >= t_prefix[t + 1]) ++t;
-            const int off = i - t_prefix[t];
-            int32_t tf0;
-            if (staged) {
+        for (int base = 0; base < total; base += BM_THREADS) {
+            const int i = base + threadIdx.x;
+            bool owner = false;
+            double score = 0.0;
+            int32_t d = 0;
+            if (i < total) {
+                int t = 0;
+                while (i >= t_prefix[t + 1]) ++t;
+                const int off = i - t_prefix[t];
                 d = st_doc[i];
-                tf0 = st_tf[i];
-            } else {
-                d = post_doc[tr[t].lo + off];
-                tf0 = post_tf[tr[t].lo + off];
-            }
-            owner = true;
-            for (int e = 0; e < t && owner; ++e) {
-                int f = staged ? find_doc(st_doc + tr[e].lds_off, tr[e].len, d)
-                               : find_doc(post_doc + tr[e].lo, tr[e].len, d);
-                if (f >= 0) owner = false;
-            }
-            if (owner) {
-                const double dl = (double)doclen[d];
-                score = __dadd_rn(0.0, bm25_contrib(t_idf[t], (double)tf0, dl, avgdl, k1, b));
-                for (int e = t + 1; e < nt; ++e) {
-                    int f;
-                    int32_t tf;
-                    if (staged) {
-                        f = find_doc(st_doc + tr[e].lds_off, tr[e].len, d);
-                        tf = f >= 0 ? st_tf[tr[e].lds_off + f] : 0;
-                    } else {
-                        f = find_doc(post_doc + tr[e].lo, tr[e].len, d);
-                        tf = f >= 0 ? post_tf[tr[e].lo + f] : 0;
+                owner = true;
+                for (int e = 0; e < t && owner; ++e)
+                    if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
+                if (owner) {
+                    const int32_t tf0 = post_tf[tr[t].lo + tr[t].cur + off];
+                    const double dl = (double)doclen[d];
+                    score = __dadd_rn(0.0, bm25_contrib(t_idf[t], (double)tf0, dl, avgdl, k1, b));
+                    for (int e = t + 1; e < nt; ++e) {
+                        const int f = find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                        if (f >= 0) {
+                            const int32_t tf = post_tf[tr[e].lo + tr[e].cur + f];
+                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tf, dl, avgdl, k1, b));
+                        }
                     }
-                    if (f >= 0)
-                        score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tf, dl, avgdl, k1, b));
                 }
             }
+            tk.push(owner, score, (int64_t)d);
         }
-        tk.push(owner, score, (int64_t)d);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 0; t < nt; ++t) tr[t].cur += tr[t].sub;
+            remaining -= total;
+            range_lo = range_hi;  // (range_lo held the "accepted" marker)
+        }
+        __syncthreads();
     }
     const int n = tk.finish();
     for (int i = threadIdx.x; i < k; i += BM_THREADS) {
@@ -166,7 +210,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                       max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
                   THR_ERR_INVALID);
     hipLaunchKernelGGL(bm25_topk_kernel, dim3(n_queries), dim3(BM_THREADS), 0, (hipStream_t)stream,
-                       rowptr, post_doc, post_tf, doclen, idf, avgdl, k1, b, id_base, query_terms,
+                       rowptr, post_doc, post_tf, doclen, idf, avgdl, k1, b, n_docs, id_base, query_terms,
                        max_terms, k, out_scores, out_ids, out_counts);
     return launch_status();
 }

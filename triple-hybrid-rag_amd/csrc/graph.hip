@@ -20,22 +20,32 @@
 //      summed left to right in float64 by the thread that owns its head
 //   5. streaming block top-k under (score desc, chunk asc)
 // Algorithmic bytes per query: S*8 + sum_hops frontier*deg*4 + reached*(16 + mentions*8).
+//
+// Two launches, no host round trip: every query first runs with SMALL on-chip capacities
+// (1024 entities / 2048 contributions: 5 workgroups per CU instead of 1), and only the queries
+// that report an overflow there are redone by the second launch with the full capacities
+// (its other workgroups exit at once).  Capacities never truncate silently: a query that
+// overflows the full ones too keeps THR_FLAG_OVERFLOW.
 #include "thr_common.hpp"
 
 namespace thr {
 
 constexpr int GR_THREADS = 256;
-constexpr int GR_SLOTS = 8192;     // hash slots (reached entities <= GR_MAX_ENT)
-constexpr int GR_MAX_ENT = 4096;
-constexpr int GR_MAX_CON = 8192;   // contributions per query
-constexpr int GR_CAP = 1024;       // BlockTopK buffer
+constexpr int GR_MAX_CON = 8192;   // contributions per query (full capacities; workspace stride)
 constexpr uint32_t GR_EMPTY = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t gr_hash(uint32_t e) { return (e * 2654435761u) >> 19; }  // 13 bits
+// on-chip capacities of one launch flavour
+struct GrSmall {
+    static constexpr int SLOTS = 2048, MAX_ENT = 1024, MAX_CON = 2048, CAP = 512;
+};
+struct GrFull {
+    static constexpr int SLOTS = 8192, MAX_ENT = 4096, MAX_CON = GR_MAX_CON, CAP = 1024;
+};
 
 // insert entity e at BFS level `lvl`; returns true if newly inserted
+template <int GR_SLOTS>
 __device__ __forceinline__ bool gr_insert(uint32_t* keys, uint8_t* dist, uint32_t e, int lvl) {
-    uint32_t h = gr_hash(e) & (GR_SLOTS - 1);
+    uint32_t h = (e * 2654435761u) >> (32 - __builtin_ctz(GR_SLOTS));
     for (int probe = 0; probe < GR_SLOTS; ++probe) {
         uint32_t old = atomicCAS(&keys[h], GR_EMPTY, e);
         if (old == GR_EMPTY) {
@@ -67,6 +77,7 @@ __device__ inline void sort_u64_asc(uint64_t* a, int n) {
         }
 }
 
+template <typename C, bool ONLY_OVERFLOWED>
 __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     const int64_t* __restrict__ ent_rowptr, const int32_t* __restrict__ ent_col, int64_t n_entities,
     const int64_t* __restrict__ men_rowptr, const int32_t* __restrict__ men_chunk,
@@ -75,10 +86,13 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     double* __restrict__ con_val_ws,  // [nq][GR_MAX_CON]
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt,
     uint32_t* __restrict__ out_flags) {
+    constexpr int GR_SLOTS = C::SLOTS, GR_MAX_ENT = C::MAX_ENT, GR_MAX_CON = C::MAX_CON,
+                  GR_CAP = C::CAP;
+    static_assert(GR_SLOTS * 5 <= GR_MAX_CON * 8, "hash set must fit the sort-key bytes");
     // LDS: phase A (BFS) uses keys/dist/frontiers; phase B reuses the same bytes for sort keys
-    __shared__ uint64_t big[GR_MAX_CON];            // 64 KiB: hash set + lists, later sort keys
-    __shared__ uint32_t reached[GR_MAX_ENT];         // 16 KiB: (entity) list, later sorted
-    __shared__ uint8_t reached_dist[GR_MAX_ENT];     //  4 KiB
+    __shared__ uint64_t big[GR_MAX_CON];            // hash set + lists, later sort keys
+    __shared__ uint32_t reached[GR_MAX_ENT];         // (entity) list, later sorted
+    __shared__ uint8_t reached_dist[GR_MAX_ENT];
     __shared__ int scan_tmp[GR_THREADS];
     __shared__ double b_s[GR_CAP];
     __shared__ int64_t b_id[GR_CAP];
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     uint8_t* hdist = reinterpret_cast<uint8_t*>(keys + GR_SLOTS);  // [GR_SLOTS]
 
     const int q = blockIdx.x;
-    double* con_val = con_val_ws + (int64_t)q * GR_MAX_CON;
+    if (ONLY_OVERFLOWED && !(out_flags[q] & THR_FLAG_OVERFLOW)) return;
+    double* con_val = con_val_ws + (int64_t)q * thr::GR_MAX_CON;
     for (int i = threadIdx.x; i < GR_SLOTS; i += GR_THREADS) keys[i] = GR_EMPTY;
     if (threadIdx.x == 0) {
         n_reached = 0;
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     // ---- level 0: seeds ----
     if (threadIdx.x < max_seeds) {
         int32_t e = query_seeds[(int64_t)q * max_seeds + threadIdx.x];
-        if (e >= 0 && e < n_entities && gr_insert(keys, hdist, (uint32_t)e, 0)) {
+        if (e >= 0 && e < n_entities && gr_insert<GR_SLOTS>(keys, hdist, (uint32_t)e, 0)) {
             int p = atomicAdd(&n_reached, 1);
             reached[p] = (uint32_t)e;
             reached_dist[p] = 0;
@@ -125,7 +140,8 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
             const int64_t lo = ent_rowptr[e], hi = ent_rowptr[e + 1];
             for (int64_t j = lo + lane; j < hi; j += WAVE) {
                 const int32_t t = ent_col[j];
-                if (t >= 0 && t < n_entities && gr_insert(keys, hdist, (uint32_t)t, lvl)) {
+                if (*(volatile int*)&overflow) break;  // the hash set must not fill up
+                if (t >= 0 && t < n_entities && gr_insert<GR_SLOTS>(keys, hdist, (uint32_t)t, lvl)) {
                     int p = atomicAdd(&n_reached, 1);
                     if (p < GR_MAX_ENT) {
                         reached[p] = (uint32_t)t;
@@ -261,9 +277,15 @@ extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col,
                       k > THR_TOPK_MAX,
                   THR_ERR_INVALID);
     THR_RETURN_IF(workspace_bytes < thr_graph_workspace_bytes(n_queries), THR_ERR_WORKSPACE);
-    hipLaunchKernelGGL(graph_topk_kernel, dim3(n_queries), dim3(GR_THREADS), 0, (hipStream_t)stream,
-                       ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk, men_conf, chunk_base,
-                       n_chunks, query_seeds, max_seeds, hops, k, (double*)workspace, out_scores,
-                       out_ids, out_counts, out_flags);
+    hipLaunchKernelGGL((graph_topk_kernel<GrSmall, false>), dim3(n_queries), dim3(GR_THREADS), 0,
+                       (hipStream_t)stream, ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk,
+                       men_conf, chunk_base, n_chunks, query_seeds, max_seeds, hops, k,
+                       (double*)workspace, out_scores, out_ids, out_counts, out_flags);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL((graph_topk_kernel<GrFull, true>), dim3(n_queries), dim3(GR_THREADS), 0,
+                       (hipStream_t)stream, ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk,
+                       men_conf, chunk_base, n_chunks, query_seeds, max_seeds, hops, k,
+                       (double*)workspace, out_scores, out_ids, out_counts, out_flags);
     return launch_status();
 }

@@ -134,8 +134,10 @@ struct BlockTopK {
         if (*count + (int)blockDim.x > CAP) compact();
     }
     __device__ void compact() {
-        bitonic_sort_desc<CAP>(s, id);
+        // slots past *count hold (-inf, INT64_MAX) already: sort only the occupied power of two
         int c = *count;
+        int n2 = next_pow2(c < 2 ? 2 : c);
+        bitonic_sort_desc_n(s, id, n2 < CAP ? n2 : CAP);
         __syncthreads();
         for (int i = threadIdx.x; i < CAP; i += blockDim.x)
             if (i >= k) {
