@@ -177,9 +177,14 @@ int thr_rrf_fuse(const int64_t *lex_ids, int n_lex, const int64_t *sem_ids, int 
  * cand [nq, n_cand] are LOCAL doc indices into dtok, negative = padding
  * (score -inf).  q_tokens, d_tokens multiples of 32; tok_dim multiple of 16. */
 int thr_maxsim(const uint16_t *qtok /* f16 [nq,q_tokens,tok_dim] */, int n_queries, int q_tokens,
-               const uint16_t *dtok /* f16 [n_docs,d_tokens,tok_dim] */, int64_t n_docs,
-               int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
-               float *out_scores /* [nq,n_cand] */, thr_stream_t stream);
+               const uint16_t *dtok /* f16 [n_docs,d_tokens,tok_dim], or its packed image */,
+               int64_t n_docs, int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
+               float *out_scores /* [nq,n_cand] */, int dtok_packed, thr_stream_t stream);
+/* Index build: re-lay the token store fragment-major ([doc][32-token tile][k-step][lane][8
+ * halves], the register image of the MFMA operand) so thr_maxsim(dtok_packed = 1) reads 1 KiB
+ * contiguous per load instruction.  Out of place; same size as dtok. */
+int thr_maxsim_pack(const uint16_t *dtok, int64_t n_docs, int d_tokens, int tok_dim,
+                    uint16_t *packed, thr_stream_t stream);
 
 /* Merge step of the multi-GPU path: G per-shard ranked lists -> global top-k under
  * (score desc, id asc).  List l of query q starts at in_*[l * list_stride + q * k_in]

@@ -61,8 +61,9 @@ def main():
            .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
            .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf))
     nt = args.token_docs
-    idx.tokens = torch.nn.functional.normalize(
+    rows = torch.nn.functional.normalize(
         torch.randn(nt, 128, 128, device="cuda", dtype=torch.float32), dim=2).to(torch.float16)
+    idx.set_tokens(rows)            # fragment-major image (thr_maxsim_pack)
     qtok = torch.nn.functional.normalize(torch.randn(nq, 32, 128, device="cuda"), dim=2).to(torch.float16)
     qd, qtd, sd = torch.from_numpy(q).cuda(), torch.from_numpy(qt).cuda(), torch.from_numpy(seeds).cuda()
     out = {"docs": n, "dim": d, "queries": nq, "input_gen_s": round(gen_s, 1)}
@@ -79,11 +80,15 @@ def main():
                     "alg_bytes_per_query_est": 8800, "GBps": round(8800 * nq / ms / 1e6, 2)}
     # maxsim: 100 candidates per query
     cand = torch.randint(0, nt, (nq, 100), device="cuda", dtype=torch.int32)
-    ms = timed(lambda: T._native.maxsim(qtok, idx.tokens, cand))
+    ms = timed(lambda: T._native.maxsim(qtok, idx.tokens, cand, packed=idx.tokens_packed))
     by = nq * 100 * 128 * 128 * 2
     fl = 2.0 * nq * 100 * 32 * 128 * 128
     out["maxsim"] = {"ms": round(ms, 3), "queries_per_s": round(nq / ms * 1e3), "GBps": round(by / ms / 1e6, 1),
-                     "frac_hbm_8TBps": round(by / ms / 1e6 / 8000, 4), "TFLOPs": round(fl / ms / 1e9, 2)}
+                     "frac_hbm_8TBps": round(by / ms / 1e6 / 8000, 4), "TFLOPs": round(fl / ms / 1e9, 2),
+                     "token_layout": "fragment-major (thr_maxsim_pack)" if idx.tokens_packed else "row-major"}
+    ms_r = timed(lambda: T._native.maxsim(qtok, rows, cand))
+    out["maxsim"]["row_major_ms"] = round(ms_r, 3)
+    del rows
     # fused pipelines
     for name, kw in (("dense_only", {}), ("dense_bm25", {"query_terms": qtd}),
                      ("triple_hybrid", {"query_terms": qtd, "query_seeds": sd})):

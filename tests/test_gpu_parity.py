@@ -266,6 +266,9 @@ def test_maxsim_matches_oracle(T):
     cand = rng.integers(0, 300, size=(6, 100)).astype(np.int32)
     cand[0, 5] = -1
     got = T._native.maxsim(dev(qt), dev(dt), dev(cand)).cpu().numpy().astype(np.float64)
+    packed = T._native.maxsim_pack(dev(dt))
+    got_p = T._native.maxsim(dev(qt), packed, dev(cand), packed=True).cpu().numpy().astype(np.float64)
+    assert np.array_equal(got, got_p)        # same products, same accumulation order
     exp = CO.maxsim(qt, dt, cand)
     assert got[0, 5] == -np.inf and exp[0, 5] == -np.inf
     ok = np.isfinite(exp)
@@ -275,8 +278,14 @@ def test_maxsim_matches_oracle(T):
     qt2 = rng.standard_normal((3, 64, 64)).astype(np.float16)
     dt2 = rng.standard_normal((40, 64, 64)).astype(np.float16)
     c2 = rng.integers(0, 40, size=(3, 7)).astype(np.int32)
+    c2[1, 3] = 40                             # out of range scores -inf, like a negative index
     got = T._native.maxsim(dev(qt2), dev(dt2), dev(c2)).cpu().numpy().astype(np.float64)
+    got_p = T._native.maxsim(dev(qt2), T._native.maxsim_pack(dev(dt2)), dev(c2), packed=True)
+    assert np.array_equal(got, got_p.cpu().numpy().astype(np.float64))
+    assert got[1, 3] == -np.inf
+    c2[1, 3] = -1
     exp = O.maxsim_scores(qt2, dt2, c2)
+    got[1, 3] = exp[1, 3] = 0.0
     assert np.max(np.abs(got - exp) / np.maximum(1.0, np.abs(exp))) < 2e-4
 
 

@@ -32,7 +32,7 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.thr_dense_topk(None, None, None, 10, 768, 0, None, 1, 10, 128, None, None, None,
                               None, None, 0, None) == -1
     assert lib.thr_dense_workspace_bytes(1_000_000, 768, 1024, 128) > 2 ** 20
-    assert lib.thr_maxsim(None, 1, 32, None, 1, 128, 128, None, 1, None, None) == -1
+    assert lib.thr_maxsim(None, 1, 32, None, 1, 128, 128, None, 1, None, 0, None) == -1
     assert lib.thr_rrf_fuse(None, 0, None, 0, None, 0, 1, 0.7, 0.8, 1.0, 60, 10, None, None, None,
                             None, None) == -1
 

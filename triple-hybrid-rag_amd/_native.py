@@ -59,7 +59,8 @@ _SIGNATURES = {
                               _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_rrf_fuse": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
                             _vp, _vp, _vp, _vp, _vp]),
-    "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "thr_maxsim_pack": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -351,7 +352,20 @@ def rrf_fuse(lex_ids, sem_ids, graph_ids, top_k: int, w_lex: float = 0.7, w_sem:
 
 
 # --------------------------------------------------------------------- a8
-def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor) -> torch.Tensor:
+def maxsim_pack(dtok: torch.Tensor) -> torch.Tensor:
+    """Row-major token store -> fragment-major image for maxsim(..., packed=True)."""
+    pdt = _dev(dtok, torch.float16, "dtok", 3)
+    nd, dt, td = dtok.shape
+    if dt % 32 or td % 16:
+        raise NativeError("maxsim: d_tokens must be a multiple of 32, tok_dim of 16")
+    out = torch.empty_like(dtok)
+    _check(load().thr_maxsim_pack(pdt, nd, dt, td, out.data_ptr(), _stream()), "thr_maxsim_pack")
+    return out
+
+
+def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor,
+           packed: bool = False) -> torch.Tensor:
+    """cand holds LOCAL doc indices; negative or out-of-range entries score -inf."""
     pq = _dev(qtok, torch.float16, "qtok", 3)
     pdt = _dev(dtok, torch.float16, "dtok", 3)
     pc = _dev(cand, torch.int32, "cand", 2)
@@ -361,11 +375,9 @@ def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor) -> torch.
         raise NativeError("maxsim: shape mismatch")
     if qt % 32 or dt % 32 or td % 16:
         raise NativeError("maxsim: q_tokens/d_tokens must be multiples of 32, tok_dim of 16")
-    if cand.numel() and int(cand.max()) >= nd:
-        raise NativeError("maxsim: candidate index out of range")
     out = torch.empty(cand.shape, dtype=torch.float32, device=qtok.device)
     _check(load().thr_maxsim(pq, nq, qt, pdt, nd, dt, td, pc, cand.shape[1], out.data_ptr(),
-                             _stream()), "thr_maxsim")
+                             1 if packed else 0, _stream()), "thr_maxsim")
     return out
 
 

@@ -52,6 +52,7 @@ class GpuIndex:
         self.lex = None
         self.graph = None
         self.tokens = None
+        self.tokens_packed = False
         self._ws: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------ builders
@@ -115,8 +116,12 @@ class GpuIndex:
                           men_conf=self._t(men_conf, torch.float32))
         return self
 
-    def set_tokens(self, dtok) -> "GpuIndex":
-        self.tokens = self._t(dtok, torch.float16)
+    def set_tokens(self, dtok, pack: bool = True) -> "GpuIndex":
+        """Late-interaction token store f16 [n, d_tokens, tok_dim].  pack=True keeps it in the
+        fragment-major layout of thr_maxsim_pack (the row-major copy is dropped)."""
+        tok = self._t(dtok, torch.float16)
+        self.tokens_packed = bool(pack)
+        self.tokens = N.maxsim_pack(tok) if pack else tok
         return self
 
     # ------------------------------------------------------------ channels
@@ -188,7 +193,7 @@ class GpuIndex:
         local = cand_global_ids - self.doc_base
         local = torch.where((local >= 0) & (local < self.tokens.shape[0]) & (cand_global_ids >= 0),
                             local, torch.full_like(local, -1)).to(torch.int32).contiguous()
-        return N.maxsim(self._t(qtok, torch.float16), self.tokens, local)
+        return N.maxsim(self._t(qtok, torch.float16), self.tokens, local, packed=self.tokens_packed)
 
     # ------------------------------------------------------------ pipeline
     def retrieve_batch(self, queries: torch.Tensor, query_terms: Optional[torch.Tensor] = None,
