@@ -159,7 +159,7 @@ def main():
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / args.probe_reps
         f16 = name != "f32"
-        qt = (64 if args.dim <= 768 else 32) if f16 else 32
+        qt = 32 if name == "f32" else (64 if name == "f16" or args.dim <= 768 else 32)
         passes = (args.queries + qt - 1) // qt
         flops = 2.0 * n_local * args.dim * args.queries
         peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS

@@ -98,20 +98,27 @@ int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs,
                          uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                          thr_stream_t stream);
 
-/* Shortlist scan on the f16 matrix cores (64 queries per pass at dim <= 768).  The float32
- * corpus stays the source of truth: scores are the same float64 rescoring of float32 rows, and
- * the certificate's error bound additionally covers row quantisation (doc_rel_err =
- * max_d ||d16-d||/||d||, measured by thr_dense_quantize_f16 into *max_rel_err, a DEVICE float)
- * and query quantisation (measured per query on the device).  Two flavours:
- *   docs16 != NULL: the scan streams a float16 COPY of the rows (half the bytes per row);
+/* Shortlist scan on the f16 matrix cores (64 queries per pass).  The float32 corpus stays the
+ * source of truth: scores are the same float64 rescoring of float32 rows, and the certificate's
+ * error bound additionally covers row quantisation (doc_rel_err = max_d ||d16-d||/||d||,
+ * measured by thr_dense_quantize_f16 into *max_rel_err, a DEVICE float) and query quantisation
+ * (measured per query on the device).  Two flavours:
+ *   docs16 != NULL: the scan streams a float16 COPY of the rows written by
+ *                   thr_dense_quantize_f16.  The copy is an opaque FRAGMENT-MAJOR image of
+ *                   thr_dense_f16_copy_bytes(n_docs, dim) bytes (rows padded to a multiple of 32):
+ *                   [row tile of 32][stage of 64 dims][16-dim quad][lane = r + 32 h][8 halves],
+ *                   the register image of the v_mfma_f32_32x32x16_f16 row operand, so the scan
+ *                   loads its fragments with coalesced 1 KiB loads and the rows never pass
+ *                   through LDS;
  *   docs16 == NULL: the scan streams the float32 rows and rounds them to float16 in registers
  *                   (no second copy; thr_dense_quantize_f16 with docs16 == NULL only measures
- *                   doc_rel_err).
+ *                   doc_rel_err; 32 queries per pass at dim 1024).
  * dim in {512, 768, 1024}; |values| must be < 65504 (doc_rel_err is +inf otherwise and
  * thr_dense_topk_f16 rejects it). */
+size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim);
 int thr_dense_quantize_f16(const float *docs, int64_t n_docs, int dim,
-                           uint16_t *docs16 /* f16 [n_docs, dim] or NULL */, float *max_rel_err,
-                           thr_stream_t stream);
+                           uint16_t *docs16 /* thr_dense_f16_copy_bytes(...) bytes, or NULL */,
+                           float *max_rel_err, thr_stream_t stream);
 size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries, int kprime);
 int thr_dense_topk_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
                        const double *dnorm, const float *inv_norm, int64_t n_docs, int dim,

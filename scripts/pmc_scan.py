@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 N_DOCS, DIM, NQ = 1_000_000, 768, 1024
 FLAVOURS = ("f16-inline", "f16", "f32")
-KERNEL_TAG = {"f32": "dense_scan_mfma2", "f16": "dense_scan_f16", "f16-inline": "dense_scan_f16"}
+KERNEL_TAG = {"f32": "dense_scan_mfma2", "f16": "dense_scan_f16p", "f16-inline": "dense_scan_f16<"}
 
 
 def run(flavour):

@@ -491,7 +491,11 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
     assert 0 < idx.doc_rel_err < 6e-4        # ~2^-12/sqrt(3) typical, 2^-11 worst case
     x16 = x.astype(np.float16)
     if mode == "f16":
-        assert np.array_equal(idx.docs16.cpu().numpy(), x16)
+        # the copy is fragment-major: [tile of 32 rows][stage of 64 dims][quad][h][r][8 halves]
+        img = idx.docs16.cpu().numpy()
+        tiles = img.shape[0] // 32
+        rows = img.reshape(tiles, d // 64, 4, 2, 32, 8).transpose(0, 4, 1, 2, 3, 5).reshape(tiles * 32, d)
+        assert np.array_equal(rows[:n], x16) and not rows[n:].any()
     else:
         assert idx.docs16 is None            # no second copy of the corpus
     nz = x.any(axis=1)

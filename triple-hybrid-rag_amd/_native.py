@@ -49,6 +49,7 @@ _SIGNATURES = {
     "thr_dense_scan_probe": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_quantize_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
+    "thr_dense_f16_copy_bytes": (_sz, [_i64, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
@@ -222,10 +223,14 @@ def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
 
 
 def dense_quantize_f16(docs: torch.Tensor, keep_copy: bool = True):
-    """-> (docs16 f16 [n, D] or None, max relative row error of the rounding as a float)."""
+    """-> (docs16 or None, max relative row error of the rounding as a float).  docs16 is the
+    fragment-major float16 image of the rows (opaque; f16 [ceil32(n), D] elements)."""
     p = _dev(docs, torch.float32, "docs", 2)
     n, d = docs.shape
-    d16 = torch.empty((n, d), dtype=torch.float16, device=docs.device) if keep_copy else None
+    d16 = None
+    if keep_copy:
+        nbytes = int(load().thr_dense_f16_copy_bytes(n, d))
+        d16 = torch.empty((nbytes // (2 * d), d), dtype=torch.float16, device=docs.device)
     err = torch.zeros(1, dtype=torch.float32, device=docs.device)
     _check(load().thr_dense_quantize_f16(p, n, d, d16.data_ptr() if keep_copy else None,
                                          err.data_ptr(), _stream()), "thr_dense_quantize_f16")
@@ -241,8 +246,8 @@ def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k
     pd = _dev(docs, torch.float32, "docs", 2)
     ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
     n, d = docs.shape
-    if docs16 is not None and tuple(docs16.shape) != (n, d):
-        raise NativeError("docs16 shape != docs shape")
+    if docs16 is not None and tuple(docs16.shape) != ((n + 31) // 32 * 32, d):
+        raise NativeError("docs16 is not the fragment-major copy of docs (thr_dense_quantize_f16)")
     pq = _dev(queries, torch.float32, "queries", 2)
     nq = queries.shape[0]
     if queries.shape[1] != d:

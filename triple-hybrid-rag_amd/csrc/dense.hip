@@ -301,6 +301,7 @@ __device__ __forceinline__ ScanSlot scan_slot(int n_qtiles) {
 
 #include "dense_scan_mfma.hpp"
 #include "dense_scan_f16.hpp"
+#include "dense_scan_f16p.hpp"
 namespace thr {
 
 // K3b: split a tile's mixed candidate list into the per-query lists K4 reads.  Each block
@@ -985,6 +986,7 @@ __global__ __launch_bounds__(256) void merge_ranked_lists(const double* __restri
 // ---------------------------------------------------------------------------
 struct DensePlan {
     int qtile, ntiles, qpad, unit, kind, row_bits;
+    bool packed;  // KIND_F16 only: scan of the fragment-major copy (else float32 rows, rounded in flight)
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
     bool sampled;
@@ -1027,18 +1029,20 @@ static int mfma_version() {
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
 // query sub-tiles of 32 per pass on the float16 copy: 2 (64 queries, 96 KiB of LDS at dim 768)
 // when the tile fits next to the transpose tiles, else 1
-static size_t f16_lds_bytes(int dim, int nq) {
+// (the fragment-major copy needs no transpose tiles: 64 queries fit at dim 1024 as well)
+static size_t f16_lds_bytes(int dim, int nq, bool packed) {
     return sizeof(_Float16) * 32 * nq * (size_t)dim +
-           (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES;
+           (sizeof(Cand) * WBUF + (packed ? 0 : sizeof(float4) * MF2_STAGE_F4)) * H_WAVES;
 }
-static int f16_nq(int dim) { return f16_lds_bytes(dim, 2) <= 160 * 1024 ? 2 : 1; }
+static int f16_nq(int dim, bool packed) { return f16_lds_bytes(dim, 2, packed) <= 160 * 1024 ? 2 : 1; }
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
-                           int dim = 0) {
+                           int dim = 0, bool packed = false) {
     DensePlan p;
     p.kind = kind;
+    p.packed = kind == KIND_F16 && packed;
     p.row_bits = kind == KIND_F16 ? ROW_BITS_F16 : ROW_BITS;
-    p.qtile = kind == KIND_F16 ? 32 * f16_nq(dim) : (use_mfma() ? MF_QT : query_tile());
+    p.qtile = kind == KIND_F16 ? 32 * f16_nq(dim, p.packed) : (use_mfma() ? MF_QT : query_tile());
     p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
@@ -1226,44 +1230,43 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
     return launch_status();
 }
 
-// rows16 != nullptr: stream the float16 copy; else stream the float32 rows and round in flight
+// rows16 != nullptr: stream the fragment-major float16 copy (dense_scan_f16p); else stream the
+// float32 rows and round them in flight (dense_scan_f16<F32IN>)
 template <int MODE>
 static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
                            const float* inv_norm, int64_t n_docs,
                            const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
                            int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    const int nq = f16_nq(dim);
-    const size_t lds = f16_lds_bytes(dim, nq);
+    const bool packed = rows16 != nullptr;
+    const int nq = f16_nq(dim, packed);
+    const size_t lds = f16_lds_bytes(dim, nq, packed);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     bool shared_rows = false;
     const dim3 grid = scan_grid(ntiles, n_row_tiles, H_WAVES, &shared_rows);
     const bool nt = scan_nt(shared_rows);
-    const bool f32_in = rows16 == nullptr;
-    const void* rows = f32_in ? (const void*)rows32 : (const void*)rows16;
-#define THR_H_LAUNCH(KERN)                                                                        \
+    const void* rows = packed ? (const void*)rows16 : (const void*)rows32;
+#define THR_H_LAUNCH(KERN, ROWS)                                                                  \
     {                                                                                             \
         auto kern = KERN;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, rows, inv_norm, n_docs, queries, \
+        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, ROWS, inv_norm, n_docs, queries, \
                            n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
                            tile_cap, sample, sample_ld);                                          \
     }
-#define THR_H_CASE(DIM, NQV)                                                                      \
+#define THR_H_CASE(DIM, NQ_INLINE)                                                                \
     case DIM:                                                                                     \
-        if (f32_in) {                                                                             \
-            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, true>))                    \
-            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, true>))                      \
+        if (packed) {                                                                             \
+            if (nt) THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, true, 2>), (const f32x4*)rows)       \
+            else THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, false, 2>), (const f32x4*)rows)         \
         } else {                                                                                  \
-            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, false>))                   \
-            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, false>))                     \
+            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQ_INLINE, true>), rows)        \
+            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQ_INLINE, true>), rows)          \
         }                                                                                         \
         break;
-    static_assert(sizeof(_Float16) * 64 * 768 + (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES <= 160 * 1024,
-                  "two query sub-tiles fit at dim 768");
-    switch (dim) {  // the sub-tile count is f16_nq(dim)
+    switch (dim) {  // sub-tile counts = f16_nq(dim, packed)
         THR_H_CASE(512, 2)
         THR_H_CASE(768, 2)
         THR_H_CASE(1024, 1)
@@ -1272,7 +1275,7 @@ static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
     }
 #undef THR_H_CASE
 #undef THR_H_LAUNCH
-    (void)nq;
+    THR_RETURN_IF(nq != (packed ? 2 : (dim == 1024 ? 1 : 2)), THR_ERR_UNSUPPORTED);
     return launch_status();
 }
 
@@ -1394,16 +1397,28 @@ extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const floa
 extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries,
                                                 int kprime) {
     if (n_docs <= 0 || n_queries <= 0) return 0;
-    return make_plan(n_docs, n_queries, kprime, KIND_F16, dim).total;
+    const size_t a = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, false).total;
+    const size_t b = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, true).total;
+    return a > b ? a : b;
+}
+
+extern "C" size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim) {
+    if (n_docs <= 0 || dim <= 0) return 0;
+    return sizeof(_Float16) * (size_t)((n_docs + 31) / 32 * 32) * (size_t)dim;
 }
 
 extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim, uint16_t* docs16,
                                       float* max_rel_err, thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!docs || !max_rel_err || n_docs <= 0 || dim <= 0, THR_ERR_INVALID);
+    THR_RETURN_IF(dim % 64 != 0, THR_ERR_UNSUPPORTED);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(max_rel_err, 0, sizeof(float), st);
     if (e != hipSuccess) return (int)e;
+    if (docs16) {  // rows past n_docs in the last tile of 32 stay zero
+        e = hipMemsetAsync(docs16, 0, thr_dense_f16_copy_bytes(n_docs, dim), st);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(quantize_f16, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, docs,
                        n_docs, dim, reinterpret_cast<_Float16*>(docs16),
                        reinterpret_cast<unsigned int*>(max_rel_err));
@@ -1423,7 +1438,7 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
     THR_RETURN_IF(!(doc_rel_err >= 0.0) || !(doc_rel_err < 1.0), THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
-    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim);
+    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, docs16 != nullptr);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
                           inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
@@ -1462,7 +1477,7 @@ extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs1
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS_F16 || n_queries <= 0,
                   THR_ERR_INVALID);
-    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim);
+    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim, docs16 != nullptr);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;

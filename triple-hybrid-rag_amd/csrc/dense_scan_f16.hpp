@@ -291,35 +291,4 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     }
 }
 
-// float32 corpus -> float16 copy (round to nearest even) + the largest relative row error
-// max_d ||d16 - d|| / ||d||, accumulated as ordered float bits with atomicMax.
-__global__ __launch_bounds__(256) void quantize_f16(const float* __restrict__ docs, int64_t n_docs,
-                                                    int dim, _Float16* __restrict__ docs16,
-                                                    unsigned int* __restrict__ max_rel_bits) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
-    if (row >= n_docs) return;
-    const float* x = docs + row * dim;
-    _Float16* y = docs16 + row * dim;
-    double err = 0.0, nrm = 0.0;
-    for (int i = lane; i < dim; i += WAVE) {
-        const float v = x[i];
-        const _Float16 hv = (_Float16)v;
-        if (docs16) y[i] = hv;  // docs16 == nullptr: measure only
-        const double d = (double)v - (double)(float)hv;
-        err += d * d;
-        nrm += (double)v * (double)v;
-    }
-    for (int m = 32; m >= 1; m >>= 1) {
-        err += __shfl_xor(err, m, WAVE);
-        nrm += __shfl_xor(nrm, m, WAVE);
-    }
-    if (lane == 0 && nrm > 0.0) {
-        // round the ratio UP to float so the stored bound is never below the true one
-        float rel = (float)sqrt(err / nrm);
-        rel = __uint_as_float(__float_as_uint(rel) + 1u);
-        atomicMax(max_rel_bits, __float_as_uint(rel));  // positive floats order like their bits
-    }
-}
-
 }  // namespace thr
