@@ -1243,7 +1243,9 @@ static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
     const size_t lds = f16_lds_bytes(dim, nq, packed);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     bool shared_rows = false;
-    const dim3 grid = scan_grid(ntiles, n_row_tiles, H_WAVES, &shared_rows);
+    // (a wave of the packed scan takes its row tiles in pairs)
+    const dim3 grid = scan_grid(ntiles, packed ? (n_row_tiles + 1) / 2 : n_row_tiles, H_WAVES,
+                                &shared_rows);
     const bool nt = scan_nt(shared_rows);
     const void* rows = packed ? (const void*)rows16 : (const void*)rows32;
 #define THR_H_LAUNCH(KERN, ROWS)                                                                  \

@@ -13,6 +13,12 @@
 // ring it multiplies from; LDS only serves the query fragments (NQ reads per quad, no writes, no
 // stage tile -- so 64 queries per pass fit at dim 1024 as well).  Rows past n_docs inside the last
 // tile are zeros in the copy and masked in the epilogue as before.
+//
+// One wave works on TWO row tiles at a time (64 rows x 64 queries, 4 accumulator tiles): a query
+// fragment read from LDS then feeds 2 MFMAs per sub-tile instead of 1.  With one row tile per
+// wave the 8 waves of a CU issued one ds_read_b128 per MFMA, which is exactly the LDS array's
+// rate (256 B/clk/CU) when the matrix pipe is full -- both ran at ~50 %.  The register ring holds
+// 2 stages of both tiles (the same 16 KiB in flight per wave; a deeper ring measured slower).
 #pragma once
 
 namespace thr {
@@ -26,13 +32,9 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16p(
     constexpr int QT = 32 * NQ;
     constexpr int CPR = DIM / 8;   // 16-byte chunks (8 halves) per query row
     constexpr int NS = DIM / 64;   // stages per row tile
-    // register ring depth = stages per unrolled group (16 KiB per wave in flight).  A ring of 6
-    // (possible at dim 768) measured slower, 1.90 vs 1.81 ms: in-flight depth is not the limit.
-    constexpr int RING = 4;
-    constexpr int NG = NS / RING;
+    constexpr int NG = NS / 4;     // groups of 4 stages; ring slots alternate 0,1,0,1 inside a group
     constexpr int QBITS = 32 - ROW_BITS_F16;
     static_assert(DIM % 256 == 0 && NG >= 2, "f16 scan needs dim % 256 == 0 and dim >= 512");
-    static_assert(NS % RING == 0, "whole groups per row tile");
     static_assert(QT <= (1 << QBITS), "query-in-tile index must fit the packed candidate word");
     extern __shared__ float4 lds_q[];  // [QT][CPR] f16 queries | H_WAVES wbufs
 
@@ -78,8 +80,11 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16p(
     const int64_t wave_id = (int64_t)slot.slice * H_WAVES + wave;
     const int64_t wave_stride = (int64_t)slot.nslices * H_WAVES;
 
-    // 16-byte index of this lane's fragment of (tile t, stage 0, quad 0); +64 per quad
+    // 16-byte index of this lane's fragment of (visited tile t, stage 0, quad 0); +64 per quad.
+    // A wave's unit of work is the PAIR of visited tiles (2P, 2P+1); a missing second tile (odd
+    // tile count) is loaded as a duplicate of the first and never emitted.
     auto frag_off = [&](int64_t t) -> int64_t { return t * tile_stride * (NS * 256) + lane; };
+    const int64_t n_pairs = (n_tiles + 1) / 2;
     const uint32_t q_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_v;
     uint32_t qrow[NQ];
 #pragma unroll
@@ -90,11 +95,14 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16p(
 
 #define THR_PIN(x) asm volatile("" : "+v"(x))
 #define PS_LD(ptr) (nt_loads ? __builtin_nontemporal_load(&packed[ptr]) : packed[ptr])
-    // the four row fragments of one stage, then on to the next stage
+    // the four row fragments of one stage of both tiles, then on to the next stage
 #define PS_LOAD(dst)                                                   \
-    THR_PIN(p);                                                        \
-    dst[0] = PS_LD(p); dst[1] = PS_LD(p + 64); dst[2] = PS_LD(p + 128); dst[3] = PS_LD(p + 192); \
-    p += 256;
+    THR_PIN(pa);                                                       \
+    dst[0] = PS_LD(pa); dst[1] = PS_LD(pa + 64); dst[2] = PS_LD(pa + 128); dst[3] = PS_LD(pa + 192); \
+    pa += 256;                                                         \
+    THR_PIN(pb);                                                       \
+    dst[4] = PS_LD(pb); dst[5] = PS_LD(pb + 64); dst[6] = PS_LD(pb + 128); dst[7] = PS_LD(pb + 192); \
+    pb += 256;
     // query fragments of one quad (one per sub-tile); qoff = chunk offset of the stage's group
 #define PS_READ(B, qoff, par, quad)                                                            \
     {                                                                                          \
@@ -109,111 +117,114 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16p(
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(B[0]), "+v"(B[NQ - 1]) : : "memory");        \
     else                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(B[0]) : : "memory");
-#define PS_MMA(A, B)                                                                            \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A),               \
-                                                    __builtin_bit_cast(half8, B[0]), acc[0], 0, 0, 0); \
+#define PS_MMA1(ACC, A, B)                                                                      \
+    ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A),               \
+                                                    __builtin_bit_cast(half8, B[0]), ACC[0], 0, 0, 0); \
     if constexpr (NQ > 1)                                                                       \
-        acc[NQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
-            __builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B[NQ - 1]), acc[NQ - 1], 0, 0, 0); \
-    asm volatile("" : "+v"(acc[0]));
-    // stage u of a group multiplies from ring slot u and refills it with the stage 4 ahead
-#define PS_STAGE(u, ringc, qcur, qnxt)                                        \
-    PS_WAIT(b0) PS_MMA(ringc[0], b0) PS_READ(b0, qcur, (u) & 1, 2)            \
-    PS_WAIT(b1) PS_MMA(ringc[1], b1) PS_READ(b1, qcur, (u) & 1, 3)            \
-    PS_WAIT(b0) PS_MMA(ringc[2], b0) PS_READ(b0, qnxt, ((u) + 1) & 1, 0)      \
-    PS_WAIT(b1) PS_MMA(ringc[3], b1) PS_READ(b1, qnxt, ((u) + 1) & 1, 1)      \
+        ACC[NQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
+            __builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B[NQ - 1]), ACC[NQ - 1], 0, 0, 0);
+#define PS_MMA(A0, A1, B)                                                                       \
+    PS_MMA1(acc_a, A0, B) PS_MMA1(acc_b, A1, B)                                                 \
+    asm volatile("" : "+v"(acc_a[0]));
+    // a stage multiplies from its ring slot (tile a: [0..3], tile b: [4..7]) and refills the slot
+    // with the stage 2 ahead
+#define PS_STAGE(u, ringc, qcur, qnxt)                                                  \
+    PS_WAIT(b0) PS_MMA(ringc[0], ringc[4], b0) PS_READ(b0, qcur, (u) & 1, 2)            \
+    PS_WAIT(b1) PS_MMA(ringc[1], ringc[5], b1) PS_READ(b1, qcur, (u) & 1, 3)            \
+    PS_WAIT(b0) PS_MMA(ringc[2], ringc[6], b0) PS_READ(b0, qnxt, ((u) + 1) & 1, 0)      \
+    PS_WAIT(b1) PS_MMA(ringc[3], ringc[7], b1) PS_READ(b1, qnxt, ((u) + 1) & 1, 1)      \
     PS_LOAD(ringc)
 
     f32x4 b0[NQ], b1[NQ];
 #pragma unroll
     for (int s = 0; s < NQ; ++s) b0[s] = b1[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ring0[4], ring1[4], ring2[4], ring3[4], ring4[4], ring5[4];
-    int64_t p = 0;
-    int64_t t = wave_id;
-    if (t < n_tiles) {
-        p = frag_off(t);
+    f32x4 ring0[8], ring1[8];
+    int64_t pa = 0, pb = 0;
+    int64_t P = wave_id;
+    auto tile_b = [&](int64_t pr) -> int64_t { return 2 * pr + 1 < n_tiles ? 2 * pr + 1 : 2 * pr; };
+    if (P < n_pairs) {
+        pa = frag_off(2 * P);
+        pb = frag_off(tile_b(P));
         PS_LOAD(ring0)
         PS_LOAD(ring1)
-        PS_LOAD(ring2)
-        PS_LOAD(ring3)
-        if constexpr (RING == 6) {
-            PS_LOAD(ring4)
-            PS_LOAD(ring5)
-        }
         PS_READ(b0, 0, 0, 0)
         PS_READ(b1, 0, 0, 1)
     }
-    for (; t < n_tiles; t += wave_stride) {
-        const int64_t row0 = t * tile_stride * MF_ROWS;
-        int idx = r;
-        if (row0 + idx >= n_docs) idx = (int)(n_docs - 1 - row0);
-        THR_PIN(idx);
-        const float my_inv = inv_norm[row0 + idx];
-        const int64_t tn = t + wave_stride < n_tiles ? t + wave_stride : t;
-        const int64_t pn = frag_off(tn);
-        f32x16 acc[NQ];
+    for (; P < n_pairs; P += wave_stride) {
+        const int64_t ta = 2 * P, tb = 2 * P + 1;
+        const bool has_b = tb < n_tiles;
+        const int64_t row0a = ta * tile_stride * MF_ROWS, row0b = (has_b ? tb : ta) * tile_stride * MF_ROWS;
+        int ia = r, ib = r;
+        if (row0a + ia >= n_docs) ia = (int)(n_docs - 1 - row0a);
+        if (row0b + ib >= n_docs) ib = (int)(n_docs - 1 - row0b);
+        THR_PIN(ia);
+        THR_PIN(ib);
+        const float inv_a = inv_norm[row0a + ia], inv_b = inv_norm[row0b + ib];
+        const int64_t Pn = P + wave_stride < n_pairs ? P + wave_stride : P;
+        const int64_t pna = frag_off(2 * Pn), pnb = frag_off(tile_b(Pn));
+        f32x16 acc_a[NQ], acc_b[NQ];
 #pragma unroll
         for (int s = 0; s < NQ; ++s)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[s][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc_a[s][i] = acc_b[s][i] = 0.f;
         // kept rolled: unrolled, every (stage, quad) LDS address becomes its own hoisted VGPR
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
-            // chunk offset of stage RING*g + u is qb + 16 * (u >> 1) (RING is even)
-            const int qb = 8 * RING * g;
-            const int qn = g + 1 < NG ? qb + 8 * RING : 0;  // first chunks of the next group / tile
-            if (g == NG - 1) p = pn;                    // the last group refills for the next tile
+            const int qb = 32 * g;                      // chunk offset of stages 4g, 4g+1
+            const int qn = g + 1 < NG ? qb + 32 : 0;    // first chunks of the next group / tile
             PS_STAGE(0, ring0, qb, qb)
             PS_STAGE(1, ring1, qb, qb + 16)
-            PS_STAGE(2, ring2, qb + 16, qb + 16)
-            if constexpr (RING == 4) {
-                PS_STAGE(3, ring3, qb + 16, qn)
-            } else {
-                PS_STAGE(3, ring3, qb + 16, qb + 32)
-                PS_STAGE(4, ring4, qb + 32, qb + 32)
-                PS_STAGE(5, ring5, qb + 32, qn)
-            }
+            // the refill issued in stage u is stage 4g+u+2: from u = 2 of the last group on, that
+            // is the head of the wave's next pair of row tiles
+            if (g == NG - 1) { pa = pna; pb = pnb; }
+            PS_STAGE(2, ring0, qb + 16, qb + 16)
+            PS_STAGE(3, ring1, qb + 16, qn)
         }
+        auto emit = [&](const f32x16* acc, int64_t t, int64_t row0, float my_inv) {
 #pragma unroll
-        for (int s = 0; s < NQ; ++s) {
-            if constexpr (MODE == MODE_ALL) {
-                // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
-                const int qg = qtile * QT + 32 * s + r;
-                float* dst = sample_scores + (int64_t)qg * sample_ld + t * MF_ROWS + 4 * h;
+            for (int s = 0; s < NQ; ++s) {
+                if constexpr (MODE == MODE_ALL) {
+                    // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
+                    const int qg = qtile * QT + 32 * s + r;
+                    float* dst = sample_scores + (int64_t)qg * sample_ld + t * MF_ROWS + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int row = j + 8 * g + 4 * h;
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = j + 8 * g + 4 * h;
+                            const float inv = __shfl(my_inv, row, WAVE);
+                            v[j] = (row0 + row < n_docs && inv > 0.f) ? acc[s][4 * g + j] * inv : -INFINITY;
+                        }
+                        *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                         const float inv = __shfl(my_inv, row, WAVE);
-                        v[j] = (row0 + row < n_docs && inv > 0.f) ? acc[s][4 * g + j] * inv : -INFINITY;
-                    }
-                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float inv = __shfl(my_inv, row, WAVE);
-                    const bool ok = row0 + row < n_docs;
-                    const float sc = acc[s][i] * inv;
-                    const bool pass = ok && inv > 0.f && sc >= my_tau[s];
-                    const uint64_t m = __ballot(pass);
-                    if (m) {
-                        const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
-                        if (pass)
-                            wbuf[pos] = Cand{sc, ((uint32_t)(32 * s + r) << ROW_BITS_F16) |
-                                                     (uint32_t)(row0 + row)};
-                        wcnt += __popcll(m);
-                        if (wcnt > WBUF - WAVE) flush();
+                        const bool ok = row0 + row < n_docs;
+                        const float sc = acc[s][i] * inv;
+                        const bool pass = ok && inv > 0.f && sc >= my_tau[s];
+                        const uint64_t m = __ballot(pass);
+                        if (m) {
+                            const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
+                            if (pass)
+                                wbuf[pos] = Cand{sc, ((uint32_t)(32 * s + r) << ROW_BITS_F16) |
+                                                         (uint32_t)(row0 + row)};
+                            wcnt += __popcll(m);
+                            if (wcnt > WBUF - WAVE) flush();
+                        }
                     }
                 }
             }
-        }
+        };
+        emit(acc_a, ta, row0a, inv_a);
+        if (has_b) emit(acc_b, tb, row0b, inv_b);
     }
 #undef PS_STAGE
 #undef PS_MMA
+#undef PS_MMA1
 #undef PS_WAIT
 #undef PS_READ
 #undef PS_LOAD
