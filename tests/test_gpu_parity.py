@@ -594,7 +594,9 @@ def test_dense_f16_rejects_rows_outside_half_range(T):
 def test_dense_edge_shapes_and_near_ties(T, shortlist):
     rng = np.random.default_rng(31)
     # tiny corpora, k > n, single query, k = 1
-    for n, d, nq, k in ((1, 768, 1, 5), (33, 768, 2, 100), (300, 512, 1, 1), (9000, 768, 3, 7)):
+    # ... and more query tiles than CUs per XCD (2100 queries = 33 tiles of 64 / 66 of 32)
+    for n, d, nq, k in ((1, 768, 1, 5), (33, 768, 2, 100), (300, 512, 1, 1), (9000, 768, 3, 7),
+                        (20001, 768, 2100, 10)):
         x = rng.standard_normal((n, d)).astype(np.float32)
         q = rng.standard_normal((nq, d)).astype(np.float32)
         idx = T.GpuIndex(doc_base=5).set_dense(x, shortlist=shortlist)

@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256) void merge_ranked_lists(const double* __restri
 // host side
 // ---------------------------------------------------------------------------
 struct DensePlan {
-    int qtile, ntiles, qpad, unit, kind, row_bits;
+    int qtile, ntiles, qpad, unit, kind, row_bits, ksample;
     bool packed;  // KIND_F16 only: scan of the fragment-major copy (else float32 rows, rounded in flight)
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
@@ -1049,12 +1049,15 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     const int64_t groups = (n_docs + p.unit - 1) / p.unit;
     // sample only when the corpus is larger than what the candidate list can hold anyway
     p.sampled = n_docs > CAND_CAP / 2;
-    // sample size: the expected number of rows passing tau is (n / sample) * k' per query;
-    // aim at 4096 (a quarter of CAND_CAP, half of a tile list's share)
-    int64_t target = n_docs * (int64_t)kprime / 4096;
-    const int64_t target_max = (int64_t)SAMPLE_TARGET * kprime / 128;
+    // tau = the ks-th best score of a sample of S rows lets (n / S) * ks rows per query through
+    // on average; aim at 4096 (a quarter of CAND_CAP, half of a tile list's share).  ks is capped
+    // at 64: the count of passing rows then spreads by ~1/8 of its mean (the tile share is 8
+    // sigma away), and the sample pass + select cost a third of what ks = k' = 192 did.
+    p.ksample = kprime < 64 ? kprime : 64;
+    int64_t target = n_docs * (int64_t)p.ksample / 4096;
+    const int64_t target_max = (int64_t)SAMPLE_TARGET * p.ksample / 128;
     if (target > target_max) target = target_max;
-    if (target < 4 * (int64_t)kprime) target = 4 * (int64_t)kprime;
+    if (target < 4 * (int64_t)p.ksample) target = 4 * (int64_t)p.ksample;
     int64_t sg = (target + p.unit - 1) / p.unit;
     if (sg > groups) sg = groups;
     p.sample_stride = sg > 0 ? groups / sg : 1;
@@ -1347,10 +1350,10 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     if (p.sampled) {
         if ((rc = scan(true, p.sample_groups, p.sample_stride, sample, p.sample_docs))) return rc;
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
-                           (int)p.sample_docs, kprime, queries, n_queries, dim, tau, qerr);
+                           (int)p.sample_docs, p.ksample, queries, n_queries, dim, tau, qerr);
     } else {
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
-                           (int64_t)0, 0, kprime, queries, n_queries, dim, tau, qerr);
+                           (int64_t)0, 0, p.ksample, queries, n_queries, dim, tau, qerr);
     }
     if ((rc = launch_status())) return rc;
     if ((rc = scan(false, p.groups, 1, nullptr, 0))) return rc;
