@@ -103,16 +103,17 @@ def main():
 
     def measure():
         """W warm-up steps, then K timed steps between barriers; max over ranks."""
-        res, rescued = None, 0
+        res, counters = None, []
         for _ in range(args.warmup):
             res = step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             res = step()
-            rescued += res.rescued
+            counters.append(res.rescued)   # device counters: a step has no host read-back
         barrier()
         elapsed = time.perf_counter() - t0
+        rescued = sum(int(c) for c in counters)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

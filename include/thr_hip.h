@@ -98,6 +98,17 @@ int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs,
                          uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                          thr_stream_t stream);
 
+/* Device-side completion of thr_dense_topk / thr_dense_topk_f16: every query whose flags lack
+ * THR_FLAG_CERTIFIED is redone on the exhaustive float64 path and overwritten in place (flags
+ * become CERTIFIED | EXACT); *n_rescued (a DEVICE int32, may be NULL) is incremented per redone
+ * query.  No host read-back: a batch runs end to end without a synchronisation. */
+size_t thr_dense_rescue_workspace_bytes(int n_queries, int k);
+int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int dim,
+                     int64_t id_base, const float *queries, int n_queries, int k,
+                     double *io_scores, int64_t *io_ids, int32_t *io_counts, uint32_t *io_flags,
+                     int32_t *n_rescued, void *workspace, size_t workspace_bytes,
+                     thr_stream_t stream);
+
 /* Shortlist scan on the f16 matrix cores (64 queries per pass).  The float32 corpus stays the
  * source of truth: scores are the same float64 rescoring of float32 rows, and the certificate's
  * error bound additionally covers row quantisation (doc_rel_err = max_d ||d16-d||/||d||,

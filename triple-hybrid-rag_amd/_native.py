@@ -47,6 +47,9 @@ _SIGNATURES = {
     "thr_dense_topk_exact": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
                                     _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "thr_dense_rescue_workspace_bytes": (_sz, [_i32, _i32]),
+    "thr_dense_rescue": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _sz, _vp]),
     "thr_dense_quantize_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "thr_dense_f16_copy_bytes": (_sz, [_i64, _i32]),
@@ -220,6 +223,31 @@ def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
     _check(load().thr_dense_scan_probe(pd, pi, n, d, pq, queries.shape[0], pw,
                                        workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_scan_probe")
+
+
+def dense_rescue_workspace_bytes(n_queries: int, k: int) -> int:
+    return int(load().thr_dense_rescue_workspace_bytes(n_queries, k))
+
+
+def dense_rescue(docs, dnorm, queries, S, I, cnt, flg, id_base: int = 0,
+                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Redo, in place and without a host read-back, the queries of a dense_topk[_f16] result
+    whose flags lack THR_FLAG_CERTIFIED.  -> device int32[1]: how many were redone."""
+    pd = _dev(docs, torch.float32, "docs", 2)
+    pn = _dev(dnorm, torch.float64, "dnorm", 1)
+    pq = _dev(queries, torch.float32, "queries", 2)
+    n, d = docs.shape
+    nq, k = I.shape
+    need = int(load().thr_dense_rescue_workspace_bytes(nq, k))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
+    n_rescued = torch.zeros(1, dtype=torch.int32, device=docs.device)
+    _check(load().thr_dense_rescue(pd, pn, n, d, id_base, pq, nq, k, S.data_ptr(), I.data_ptr(),
+                                   cnt.data_ptr(), flg.data_ptr(), n_rescued.data_ptr(),
+                                   workspace.data_ptr(),
+                                   workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_rescue")
+    return n_rescued
 
 
 def dense_quantize_f16(docs: torch.Tensor, keep_copy: bool = True):

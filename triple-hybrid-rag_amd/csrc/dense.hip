@@ -827,8 +827,10 @@ constexpr int EX_SLABS = 64;
 __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int64_t n_docs, int dim,
     const float* __restrict__ queries, int k, double* __restrict__ slab_s,
-    int64_t* __restrict__ slab_id) {
+    int64_t* __restrict__ slab_id, const uint32_t* __restrict__ skip_certified) {
     extern __shared__ float lds_qv[];
+    // rescue mode: only the queries the certificate could not prove (the others exit at once)
+    if (skip_certified && (skip_certified[blockIdx.y] & THR_FLAG_CERTIFIED)) return;
     __shared__ double b_s[EX_CAP];
     __shared__ int64_t b_id[EX_CAP];
     __shared__ int b_cnt;
@@ -874,7 +876,11 @@ __global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in
                                                    double* __restrict__ out_s,
                                                    int64_t* __restrict__ out_id,
                                                    int32_t* __restrict__ out_counts,
-                                                   uint32_t* __restrict__ out_flags) {
+                                                   uint32_t* __restrict__ out_flags,
+                                                   const uint32_t* __restrict__ skip_certified = nullptr,
+                                                   int32_t* __restrict__ n_done = nullptr) {
+    if (skip_certified && (skip_certified[blockIdx.x] & THR_FLAG_CERTIFIED)) return;
+    if (n_done && threadIdx.x == 0) atomicAdd(n_done, 1);
     __shared__ double b_s[EX_CAP];
     __shared__ int64_t b_id[EX_CAP];
     __shared__ int b_cnt;
@@ -1517,13 +1523,50 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
     int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
     hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
                        sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, k, slab_s,
-                       slab_id);
+                       slab_id, (const uint32_t*)nullptr);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
                        (int64_t)EX_SLABS * k, (int64_t)k, EX_SLABS, k, k, id_base,
                        THR_FLAG_CERTIFIED | THR_FLAG_EXACT, out_scores, out_ids, out_counts,
                        out_flags);
+    return launch_status();
+}
+
+extern "C" size_t thr_dense_rescue_workspace_bytes(int n_queries, int k) {
+    if (n_queries <= 0 || k <= 0) return 0;
+    return (size_t)n_queries * EX_SLABS * (size_t)k * (sizeof(double) + sizeof(int64_t));
+}
+
+// Device-side completion of thr_dense_topk[_f16]: the queries whose flags lack
+// THR_FLAG_CERTIFIED are redone on the exhaustive float64 path, in place, with no host read-back
+// (workgroups of certified queries exit at once).  *n_rescued (device int32) is incremented
+// once per redone query.
+extern "C" int thr_dense_rescue(const float* docs, const double* dnorm, int64_t n_docs, int dim,
+                                int64_t id_base, const float* queries, int n_queries, int k,
+                                double* io_scores, int64_t* io_ids, int32_t* io_counts,
+                                uint32_t* io_flags, int32_t* n_rescued, void* workspace,
+                                size_t workspace_bytes, thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!docs || !dnorm || !queries || !io_scores || !io_ids || !io_counts ||
+                      !io_flags || !workspace,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || k > THR_DENSE_MAX_K, THR_ERR_INVALID);
+    THR_RETURN_IF(dim <= 0 || dim % 4 != 0, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(workspace_bytes < thr_dense_rescue_workspace_bytes(n_queries, k),
+                  THR_ERR_WORKSPACE);
+    hipStream_t st = (hipStream_t)stream;
+    double* slab_s = (double*)workspace;
+    int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
+    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
+                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, k, slab_s,
+                       slab_id, (const uint32_t*)io_flags);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
+                       (int64_t)EX_SLABS * k, (int64_t)k, EX_SLABS, k, k, id_base,
+                       THR_FLAG_CERTIFIED | THR_FLAG_EXACT, io_scores, io_ids, io_counts, io_flags,
+                       (const uint32_t*)io_flags, n_rescued);
     return launch_status();
 }
 

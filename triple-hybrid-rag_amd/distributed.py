@@ -81,7 +81,7 @@ class ShardedIndex:
         w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
         w.update(weights or {})
         L = self.local
-        Ss, Is, _, nres = L.dense_search(queries, semantic_top_k)
+        Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False)
         Ss, Is = self._merge(Ss, Is, semantic_top_k)
         Il = Ig = None
         if query_terms is not None and L.lex is not None:

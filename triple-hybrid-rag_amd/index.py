@@ -34,7 +34,9 @@ class BatchResult:
     scores: torch.Tensor         # float64 [nq, top_k] RRF scores (rerank: MaxSim scores)
     counts: torch.Tensor         # int32 [nq]
     channels: Dict[str, tuple] = field(default_factory=dict)  # name -> (scores, ids, counts)
-    rescued: int = 0             # queries that needed the exhaustive float64 path
+    # queries that needed the exhaustive float64 path: an int, or (batch path, so that a batch
+    # needs no host synchronisation) a device int32[1] -- int(result.rescued) reads it back
+    rescued: object = 0
 
 
 class GpuIndex:
@@ -54,6 +56,7 @@ class GpuIndex:
         self.tokens = None
         self.tokens_packed = False
         self._ws: Optional[torch.Tensor] = None
+        self._ws_rescue: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------ builders
     def _t(self, a, dtype):
@@ -131,10 +134,11 @@ class GpuIndex:
         return self._ws
 
     def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
-                     rescue: bool = True):
+                     rescue: bool = True, sync: bool = True):
         """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
-        fp32-error certificate cannot prove exact (massive ties / duplicates) are redone on
-        the exhaustive float64 path; that check reads the flags back (one sync per batch)."""
+        error-bound certificate cannot prove exact (massive ties / duplicates) are redone on the
+        exhaustive float64 path, on the device (thr_dense_rescue: no host read-back).
+        n_rescued is an int, or with sync=False the device int32[1] it would be read from."""
         queries = self._t(queries, torch.float32)
         if self.shortlist != "f32":
             # tau must sit clearly below the k-th score for the quantisation-aware certificate:
@@ -151,13 +155,13 @@ class GpuIndex:
                                           self.doc_base, ws)
         n_rescued = 0
         if rescue:
-            # one small reduction + one read-back per batch; the index list only when needed
-            n_rescued = int(flg.numel()) - int((flg & N.THR_FLAG_CERTIFIED).sum())  # flag bit = 1
-            if n_rescued:
-                bad = torch.nonzero((flg & N.THR_FLAG_CERTIFIED) == 0).flatten()
-                S2, I2, c2, _ = N.dense_topk_exact(self.docs, self.dnorm,
-                                                   queries[bad].contiguous(), k, self.doc_base)
-                S[bad], I[bad], cnt[bad] = S2, I2, c2
+            need = N.dense_rescue_workspace_bytes(queries.shape[0], k)
+            if self._ws_rescue is None or self._ws_rescue.numel() < need:
+                self._ws_rescue = torch.empty(need, dtype=torch.uint8, device=self.device)
+            n_rescued = N.dense_rescue(self.docs, self.dnorm, queries, S, I, cnt, flg,
+                                       self.doc_base, self._ws_rescue)
+            if sync:
+                n_rescued = int(n_rescued)
         return S, I, cnt, n_rescued
 
     def scan_probe(self, queries: torch.Tensor) -> None:
@@ -207,7 +211,7 @@ class GpuIndex:
         w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
         w.update(weights or {})
         ch = {}
-        Ss, Is, Cs, nres = self.dense_search(queries, semantic_top_k, rescue=rescue)
+        Ss, Is, Cs, nres = self.dense_search(queries, semantic_top_k, rescue=rescue, sync=False)
         ch["semantic"] = (Ss, Is, Cs)
         Il = Ig = None
         if query_terms is not None and self.lex is not None:
