@@ -826,44 +826,48 @@ constexpr int EX_SLABS = 64;
 
 __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int64_t n_docs, int dim,
-    const float* __restrict__ queries, int k, double* __restrict__ slab_s,
+    const float* __restrict__ queries, int n_queries, int k, double* __restrict__ slab_s,
     int64_t* __restrict__ slab_id, const uint32_t* __restrict__ skip_certified) {
     extern __shared__ float lds_qv[];
-    // rescue mode: only the queries the certificate could not prove (the others exit at once)
-    if (skip_certified && (skip_certified[blockIdx.y] & THR_FLAG_CERTIFIED)) return;
     __shared__ double b_s[EX_CAP];
     __shared__ int64_t b_id[EX_CAP];
     __shared__ int b_cnt;
     __shared__ double t_s;
     __shared__ int64_t t_id;
     __shared__ double s_qn;
-    const int q = blockIdx.y, slab = blockIdx.x;
-    for (int i = threadIdx.x; i < dim; i += EX_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
-    __syncthreads();
-    if (threadIdx.x == 0) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
-    BlockTopK<EX_CAP> tk;
-    tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k);
-    const double qn = s_qn;
-    const int64_t per = (n_docs + EX_SLABS - 1) / EX_SLABS;
-    const int64_t lo = slab * per, hi = (lo + per < n_docs) ? lo + per : n_docs;
-    for (int64_t base = lo; base < hi; base += EX_THREADS) {
-        int64_t row = base + threadIdx.x;
-        bool ok = row < hi;
-        double sim = -INFINITY;
-        if (ok) {
-            double dn = dnorm[row];
-            if (dn > 0.0) {
-                double dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
-                sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
+    const int slab = blockIdx.x;
+    // queries strided over gridDim.y: in rescue mode (skip_certified) the grid is small and a
+    // block walks past the certified queries, instead of one mostly-empty block per query
+    for (int q = blockIdx.y; q < n_queries; q += gridDim.y) {
+        if (skip_certified && (skip_certified[q] & THR_FLAG_CERTIFIED)) continue;
+        __syncthreads();
+        for (int i = threadIdx.x; i < dim; i += EX_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
+        __syncthreads();
+        if (threadIdx.x == 0) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
+        BlockTopK<EX_CAP> tk;
+        tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k);
+        const double qn = s_qn;
+        const int64_t per = (n_docs + EX_SLABS - 1) / EX_SLABS;
+        const int64_t lo = slab * per, hi = (lo + per < n_docs) ? lo + per : n_docs;
+        for (int64_t base = lo; base < hi; base += EX_THREADS) {
+            int64_t row = base + threadIdx.x;
+            bool ok = row < hi;
+            double sim = -INFINITY;
+            if (ok) {
+                double dn = dnorm[row];
+                if (dn > 0.0) {
+                    double dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
+                    sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
+                }
             }
+            tk.push(ok && sim > -INFINITY, sim, row);
         }
-        tk.push(ok && sim > -INFINITY, sim, row);
-    }
-    int n = tk.finish();
-    for (int i = threadIdx.x; i < k; i += EX_THREADS) {
-        int64_t o = ((int64_t)q * EX_SLABS + slab) * k + i;
-        slab_s[o] = i < n ? b_s[i] : -INFINITY;
-        slab_id[o] = i < n ? b_id[i] : INT64_MAX;
+        int n = tk.finish();
+        for (int i = threadIdx.x; i < k; i += EX_THREADS) {
+            int64_t o = ((int64_t)q * EX_SLABS + slab) * k + i;
+            slab_s[o] = i < n ? b_s[i] : -INFINITY;
+            slab_id[o] = i < n ? b_id[i] : INT64_MAX;
+        }
     }
 }
 
@@ -1522,8 +1526,8 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
     double* slab_s = (double*)workspace;
     int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
     hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
-                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, k, slab_s,
-                       slab_id, (const uint32_t*)nullptr);
+                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, n_queries, k,
+                       slab_s, slab_id, (const uint32_t*)nullptr);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
@@ -1558,9 +1562,9 @@ extern "C" int thr_dense_rescue(const float* docs, const double* dnorm, int64_t 
     hipStream_t st = (hipStream_t)stream;
     double* slab_s = (double*)workspace;
     int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
-    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
-                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, k, slab_s,
-                       slab_id, (const uint32_t*)io_flags);
+    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries < 32 ? n_queries : 32),
+                       dim3(EX_THREADS), sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries,
+                       n_queries, k, slab_s, slab_id, (const uint32_t*)io_flags);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
