@@ -835,11 +835,21 @@ __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
     __shared__ double t_s;
     __shared__ int64_t t_id;
     __shared__ double s_qn;
+    __shared__ unsigned long long s_todo;
     const int slab = blockIdx.x;
-    // queries strided over gridDim.y: in rescue mode (skip_certified) the grid is small and a
-    // block walks past the certified queries, instead of one mostly-empty block per query
-    for (int q = blockIdx.y; q < n_queries; q += gridDim.y) {
-        if (skip_certified && (skip_certified[q] & THR_FLAG_CERTIFIED)) continue;
+    // queries strided over gridDim.y, at most 64 per block: in rescue mode (skip_certified) the
+    // grid is small and one ballot tells the block which of its queries still need the work
+    // (instead of one mostly-empty block per query)
+    {
+        const int q = blockIdx.y + (int)threadIdx.x * (int)gridDim.y;
+        const bool todo = threadIdx.x < 64 && q < n_queries &&
+                          !(skip_certified && (skip_certified[q] & THR_FLAG_CERTIFIED));
+        const unsigned long long m = __ballot(todo);
+        if (threadIdx.x == 0) s_todo = m;
+        __syncthreads();
+    }
+    for (unsigned long long todo = s_todo; todo; todo &= todo - 1) {
+        const int q = blockIdx.y + (__ffsll((long long)todo) - 1) * (int)gridDim.y;
         __syncthreads();
         for (int i = threadIdx.x; i < dim; i += EX_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
         __syncthreads();
@@ -1562,9 +1572,10 @@ extern "C" int thr_dense_rescue(const float* docs, const double* dnorm, int64_t 
     hipStream_t st = (hipStream_t)stream;
     double* slab_s = (double*)workspace;
     int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
-    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries < 32 ? n_queries : 32),
-                       dim3(EX_THREADS), sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries,
-                       n_queries, k, slab_s, slab_id, (const uint32_t*)io_flags);
+    const int rows = (n_queries + 63) / 64 > 16 ? (n_queries + 63) / 64 : (n_queries < 16 ? n_queries : 16);
+    hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, rows), dim3(EX_THREADS),
+                       sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, n_queries, k,
+                       slab_s, slab_id, (const uint32_t*)io_flags);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
