@@ -67,6 +67,7 @@ class GpuIndex:
     SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
     F16_DIMS = (512, 768, 1024)
     AUTO_COPY_FRACTION = 0.10
+    F16_MAX_ROWS = 1 << 26       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
 
     def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
@@ -87,7 +88,7 @@ class GpuIndex:
         auto = shortlist == "auto"
         if auto:
             shortlist = "f32"
-            if self.dim in self.F16_DIMS:
+            if self.dim in self.F16_DIMS and self.n_docs < self.F16_MAX_ROWS:
                 total = torch.cuda.get_device_properties(self.device).total_memory
                 copy_bytes = 2 * self.n_docs * self.dim
                 shortlist = "f16" if copy_bytes <= self.AUTO_COPY_FRACTION * total else "f16-inline"
