@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of ``--queries`` synthetic queries:
+A step = one pass of the hot path over one batch of ``--queries`` (default 1536) synthetic queries:
 dense brute-force cosine top-100 over the HBM-resident corpus -> (all-gather + merge when
 N > 1) -> weighted RRF -> fused top-10.  Workload at N = 1 is BASELINE.json configs[1]
 (1M-doc / 768-d dense-only top-10).  For N > 1 the SAME corpus is sharded by document
@@ -48,10 +48,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--queries", type=int, default=1024, help="queries per step (batch)")
+    ap.add_argument("--queries", type=int, default=1536,
+                    help="queries per step (batch): 1536 = 16 tiles of 96 queries, one full round "
+                         "of the 256 CUs for the default scan (1024 = 16 tiles of 64)")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=1024)
+    ap.add_argument("--cpu-queries", type=int, default=1536)
     ap.add_argument("--probe-reps", type=int, default=5)
     ap.add_argument("--no-extras", "--no-f16-extra", dest="no_extras", action="store_true",
                     help="skip the measurements of the other shortlist flavours reported next to "
@@ -160,7 +162,8 @@ def main():
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / args.probe_reps
         f16 = name != "f32"
-        qt = 32 if name == "f32" else (64 if name == "f16" or args.dim <= 768 else 32)
+        qt = 32 if name == "f32" else T._native.dense_f16_query_tile(args.dim, name == "f16",
+                                                                      args.queries)
         passes = (args.queries + qt - 1) // qt
         flops = 2.0 * n_local * args.dim * args.queries
         peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS

@@ -109,7 +109,7 @@ int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int
                      int32_t *n_rescued, void *workspace, size_t workspace_bytes,
                      thr_stream_t stream);
 
-/* Shortlist scan on the f16 matrix cores (64 queries per pass).  The float32 corpus stays the
+/* Shortlist scan on the f16 matrix cores (64 or 96 queries per pass; < 2^25 rows per shard).  The float32 corpus stays the
  * source of truth: scores are the same float64 rescoring of float32 rows, and the certificate's
  * error bound additionally covers row quantisation (doc_rel_err = max_d ||d16-d||/||d||,
  * measured by thr_dense_quantize_f16 into *max_rel_err, a DEVICE float) and query quantisation
@@ -127,6 +127,9 @@ int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int
  * dim in {512, 768, 1024}; |values| must be < 65504 (doc_rel_err is +inf otherwise and
  * thr_dense_topk_f16 rejects it). */
 size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim);
+/* queries per row pass the f16 scan uses for a batch of n_queries (64, or 96 when that fills the
+ * CUs better; 32 for the in-flight-rounding flavour at dim 1024) */
+int thr_dense_f16_query_tile(int dim, int packed /* docs16 != NULL */, int n_queries);
 int thr_dense_quantize_f16(const float *docs, int64_t n_docs, int dim,
                            uint16_t *docs16 /* thr_dense_f16_copy_bytes(...) bytes, or NULL */,
                            float *max_rel_err, thr_stream_t stream);

@@ -2,7 +2,7 @@
 """PMC passes over the dense scan kernels (how profiles/r1_dense_scan_traffic.json is made).
 
   run FLAVOUR            launch the scan of one shortlist flavour a few times at the bench shape
-                         (1M x 768, 1024 queries); meant to sit behind rocprofv3, one counter set
+                         (1M x 768, 1536 queries); meant to sit behind rocprofv3, one counter set
                          per pass (MI355X_MICROARCH.md, HBM / rocprofv3):
       rocprofv3 --pmc FETCH_SIZE --kernel-trace -d D -o fetch_F -- python3 scripts/pmc_scan.py run F
       rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace \
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-N_DOCS, DIM, NQ = 1_000_000, 768, 1024
+N_DOCS, DIM, NQ = 1_000_000, 768, 1536
 FLAVOURS = ("f16-inline", "f16", "f32")
 KERNEL_TAG = {"f32": "dense_scan_mfma2", "f16": "dense_scan_f16p", "f16-inline": "dense_scan_f16<"}
 
@@ -99,7 +99,7 @@ def parse(d, out_path):
                 e["effective_clock_ghz"] = round(gui / 8 / ns, 3)
                 e["mfma_busy"] = round(busy / (gui / 8 * 256 * 4) , 4) if gui else None
                 e["launch_ms_under_pmc"] = round(ns / 1e6, 4)
-        passes = NQ // (32 if fl == "f32" else 64)
+        passes = -(-NQ // {"f32": 32, "f16-inline": 64, "f16": 96}[fl])   # bench shape: 1536 queries
         e["passes"] = passes
         e["algorithmic_bytes_per_launch_8d"] = passes * N_DOCS * DIM * (2 if fl == "f16" else 4)
         e["one_corpus_pass_bytes"] = N_DOCS * DIM * (2 if fl == "f16" else 4)

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "thr_dense_quantize_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "thr_dense_f16_copy_bytes": (_sz, [_i64, _i32]),
+    "thr_dense_f16_query_tile": (_i32, [_i32, _i32, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
@@ -223,6 +224,10 @@ def dense_scan_probe(docs, inv_norm, queries, workspace: torch.Tensor) -> None:
     _check(load().thr_dense_scan_probe(pd, pi, n, d, pq, queries.shape[0], pw,
                                        workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_scan_probe")
+
+
+def dense_f16_query_tile(dim: int, packed: bool, n_queries: int) -> int:
+    return int(load().thr_dense_f16_query_tile(dim, 1 if packed else 0, n_queries))
 
 
 def dense_rescue_workspace_bytes(n_queries: int, k: int) -> int:

@@ -32,7 +32,7 @@ constexpr int SAMPLE_TARGET = 32768;       // sample docs for the tau estimate
 constexpr int WBUF = 256;                  // per-wave LDS staging slots for passing rows
 constexpr int ROW_BITS = 27;               // tile-list entries pack (query-in-tile << 27 | row)
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
-constexpr int ROW_BITS_F16 = 26;           // f16 shortlist scan: 64 queries per tile -> 6 bits
+constexpr int ROW_BITS_F16 = 25;           // f16 shortlist scans: up to 96 queries per tile -> 7 bits
 
 struct Cand {
     float score;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__
                                                          int tile_cap, int qtile, int row_bits,
                                                          int* __restrict__ cand_cnt,
                                                          Cand* __restrict__ cand) {
-    __shared__ int count[64], base[64], fill[64];
+    __shared__ int count[128], base[128], fill[128];
     const uint32_t row_mask = (1u << row_bits) - 1u;
     const int tile = blockIdx.y;
     int n = tile_cnt[tile];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void bucket_candidates(const int* __restrict__
     const int per = (n + gridDim.x - 1) / gridDim.x;
     const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     const Cand* list = tile_list + (int64_t)tile * tile_cap;
-    if (threadIdx.x < 64) count[threadIdx.x] = fill[threadIdx.x] = 0;
+    if (threadIdx.x < 128) count[threadIdx.x] = fill[threadIdx.x] = 0;
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x)
         atomicAdd(&count[list[i].doc >> row_bits], 1);
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void merge_ranked_lists(const double* __restri
 // host side
 // ---------------------------------------------------------------------------
 struct DensePlan {
-    int qtile, ntiles, qpad, unit, kind, row_bits, ksample;
+    int qtile, ntiles, qpad, unit, kind, row_bits, ksample, nq;
     bool packed;  // KIND_F16 only: scan of the fragment-major copy (else float32 rows, rounded in flight)
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
@@ -1054,15 +1054,38 @@ static size_t f16_lds_bytes(int dim, int nq, bool packed) {
     return sizeof(_Float16) * 32 * nq * (size_t)dim +
            (sizeof(Cand) * WBUF + (packed ? 0 : sizeof(float4) * MF2_STAGE_F4)) * H_WAVES;
 }
-static int f16_nq(int dim, bool packed) { return f16_lds_bytes(dim, 2, packed) <= 160 * 1024 ? 2 : 1; }
+// Query sub-tiles of 32 per pass.  Inline flavour: 2 when the tile fits next to the transpose
+// tiles, else 1.  Packed flavour: 2, or 3 (96 queries: a third fewer row bytes per MFMA, but
+// ~1.2x the time per block) when it fits LDS and the batch's tile count then keeps the CUs
+// busier -- e.g. 1536 queries are 16 tiles of 96 (all 256 CUs, one round) but 24 tiles of 64
+// (192 CUs, twice the rows each); 1024 queries are 16 tiles of 64 but 11 of 96.
+static int f16_pick_nq(int dim, bool packed, int n_queries) {
+    if (!packed) return f16_lds_bytes(dim, 2, false) <= 160 * 1024 ? 2 : 1;
+    if (f16_lds_bytes(dim, 3, true) > 160 * 1024) return 2;
+    static int forced = -1;  // THR_DENSE_F16_NQ=2|3 pins the choice
+    if (forced < 0) {
+        const char* e = getenv("THR_DENSE_F16_NQ");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 2 || forced == 3) return forced;
+    auto cost = [&](int nq) {
+        const int ntq = (n_queries + 32 * nq - 1) / (32 * nq);
+        int m = 32 / ntq;            // slices per XCD that run at once (scan_grid's choice when it divides)
+        if (m < 1) m = 1;
+        const int rounds = (8 * m * ntq + 255) / 256;
+        return (nq == 3 ? 1.2 : 1.0) * (double)rounds / (double)m;
+    };
+    return cost(3) < cost(2) ? 3 : 2;
+}
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
                            int dim = 0, bool packed = false) {
     DensePlan p;
     p.kind = kind;
     p.packed = kind == KIND_F16 && packed;
+    p.nq = kind == KIND_F16 ? f16_pick_nq(dim, p.packed, n_queries) : 1;
     p.row_bits = kind == KIND_F16 ? ROW_BITS_F16 : ROW_BITS;
-    p.qtile = kind == KIND_F16 ? 32 * f16_nq(dim, p.packed) : (use_mfma() ? MF_QT : query_tile());
+    p.qtile = kind == KIND_F16 ? 32 * p.nq : (use_mfma() ? MF_QT : query_tile());
     p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
@@ -1256,13 +1279,12 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
 // rows16 != nullptr: stream the fragment-major float16 copy (dense_scan_f16p); else stream the
 // float32 rows and round them in flight (dense_scan_f16<F32IN>)
 template <int MODE>
-static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
+static int launch_scan_f16(int dim, int nq, const float* rows32, const _Float16* rows16,
                            const float* inv_norm, int64_t n_docs,
                            const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
                            int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
     const bool packed = rows16 != nullptr;
-    const int nq = f16_nq(dim, packed);
     const size_t lds = f16_lds_bytes(dim, nq, packed);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     bool shared_rows = false;
@@ -1281,26 +1303,37 @@ static int launch_scan_f16(int dim, const float* rows32, const _Float16* rows16,
                            n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
                            tile_cap, sample, sample_ld);                                          \
     }
-#define THR_H_CASE(DIM, NQ_INLINE)                                                                \
-    case DIM:                                                                                     \
-        if (packed) {                                                                             \
-            if (nt) THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, true, 2>), (const f32x4*)rows)       \
-            else THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, false, 2>), (const f32x4*)rows)         \
-        } else {                                                                                  \
-            if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQ_INLINE, true>), rows)        \
-            else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQ_INLINE, true>), rows)          \
-        }                                                                                         \
-        break;
-    switch (dim) {  // sub-tile counts = f16_nq(dim, packed)
-        THR_H_CASE(512, 2)
-        THR_H_CASE(768, 2)
-        THR_H_CASE(1024, 1)
-        default:
-            return THR_ERR_UNSUPPORTED;
+#define THR_H_PACKED(DIM, NQV)                                                                    \
+    {                                                                                             \
+        if (nt) THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, true, NQV>), (const f32x4*)rows)         \
+        else THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, false, NQV>), (const f32x4*)rows)           \
     }
-#undef THR_H_CASE
+#define THR_H_INLINE(DIM, NQV)                                                                    \
+    {                                                                                             \
+        if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, true>), rows)                  \
+        else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, true>), rows)                    \
+    }
+    const int key = dim * 10 + nq;
+    if (packed) {
+        switch (key) {
+            case 5122: THR_H_PACKED(512, 2) break;
+            case 5123: THR_H_PACKED(512, 3) break;
+            case 7682: THR_H_PACKED(768, 2) break;
+            case 7683: THR_H_PACKED(768, 3) break;
+            case 10242: THR_H_PACKED(1024, 2) break;
+            default: return THR_ERR_UNSUPPORTED;
+        }
+    } else {
+        switch (key) {
+            case 5122: THR_H_INLINE(512, 2) break;
+            case 7682: THR_H_INLINE(768, 2) break;
+            case 10241: THR_H_INLINE(1024, 1) break;
+            default: return THR_ERR_UNSUPPORTED;
+        }
+    }
+#undef THR_H_INLINE
+#undef THR_H_PACKED
 #undef THR_H_LAUNCH
-    THR_RETURN_IF(nq != (packed ? 2 : (dim == 1024 ? 1 : 2)), THR_ERR_UNSUPPORTED);
     return launch_status();
 }
 
@@ -1351,10 +1384,10 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     float* sample = (float*)(ws + p.off_sample);
     auto scan = [&](bool all, int64_t units, int64_t stride, float* smp, int64_t ld) -> int {
         if (h)
-            return all ? launch_scan_f16<MODE_ALL>(dim, docs, docs16, inv_norm, n_docs, queries,
+            return all ? launch_scan_f16<MODE_ALL>(dim, p.nq, docs, docs16, inv_norm, n_docs, queries,
                                                    n_queries, p.ntiles, units, stride, nullptr,
                                                    nullptr, nullptr, 0, smp, ld, st)
-                       : launch_scan_f16<MODE_FILTER>(dim, docs, docs16, inv_norm, n_docs, queries,
+                       : launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, docs16, inv_norm, n_docs, queries,
                                                       n_queries, p.ntiles, units, stride, tau, tcnt,
                                                       tlist, p.tile_cap, nullptr, 0, st);
         return all ? launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
@@ -1425,6 +1458,11 @@ extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_q
     const size_t a = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, false).total;
     const size_t b = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, true).total;
     return a > b ? a : b;
+}
+
+extern "C" int thr_dense_f16_query_tile(int dim, int packed, int n_queries) {
+    if (dim != 512 && dim != 768 && dim != 1024) return 0;
+    return 32 * f16_pick_nq(dim, packed != 0, n_queries > 0 ? n_queries : 1);
 }
 
 extern "C" size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim) {
@@ -1508,7 +1546,7 @@ extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs1
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
-    return launch_scan_f16<MODE_FILTER>(dim, docs, reinterpret_cast<const _Float16*>(docs16), inv_norm,
+    return launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, reinterpret_cast<const _Float16*>(docs16), inv_norm,
                                         n_docs, queries, n_queries, p.ntiles, p.groups, 1,
                                         (const float*)(ws + p.off_tau), (int*)(ws + p.off_tcnt),
                                         (Cand*)(ws + p.off_tlist), p.tile_cap, nullptr, 0, st);

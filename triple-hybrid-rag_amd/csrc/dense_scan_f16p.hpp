@@ -12,7 +12,9 @@
 // then loads its fragments with fully coalesced 1 KiB global loads straight into the register
 // ring it multiplies from; LDS only serves the query fragments (NQ reads per quad, no writes, no
 // stage tile -- so 64 queries per pass fit at dim 1024 as well).  Rows past n_docs inside the last
-// tile are zeros in the copy and masked in the epilogue as before.
+// tile are zeros in the copy and masked in the epilogue as before.  NQ = 3 (96 queries per pass,
+// 144 KiB of LDS at dim 768, exactly 256 VGPRs) cuts the row bytes per MFMA by a third: the
+// host picks it when the batch's tile count then fills the CUs better (f16_pick_nq).
 //
 // One wave works on TWO row tiles at a time (64 rows x 64 queries, 4 accumulator tiles): a query
 // fragment read from LDS then feeds 2 MFMAs per sub-tile instead of 1.  With one row tile per
@@ -109,20 +111,27 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16p(
         const uint32_t cb = (uint32_t)((qoff) + qlow[(par) * 4 + (quad)]) * 16u;               \
         asm volatile("ds_read_b128 %0, %1" : "=v"(B[0]) : "v"(qrow[0] + cb) : "memory");       \
         if constexpr (NQ > 1)                                                                  \
-            asm volatile("ds_read_b128 %0, %1" : "=v"(B[NQ - 1]) : "v"(qrow[NQ - 1] + cb) : "memory"); \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(B[1]) : "v"(qrow[1] + cb) : "memory");   \
+        if constexpr (NQ > 2)                                                                  \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(B[2]) : "v"(qrow[2] + cb) : "memory");   \
     }
     // the other pending set (NQ reads) is the only thing younger than the set waited for
 #define PS_WAIT(B)                                                                              \
-    if constexpr (NQ > 1)                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(B[0]), "+v"(B[NQ - 1]) : : "memory");        \
+    if constexpr (NQ == 3)                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(B[0]), "+v"(B[1]), "+v"(B[2]) : : "memory"); \
+    else if constexpr (NQ == 2)                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(B[0]), "+v"(B[1]) : : "memory");             \
     else                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(B[0]) : : "memory");
 #define PS_MMA1(ACC, A, B)                                                                      \
     ACC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, A),               \
                                                     __builtin_bit_cast(half8, B[0]), ACC[0], 0, 0, 0); \
     if constexpr (NQ > 1)                                                                       \
-        ACC[NQ - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                   \
-            __builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B[NQ - 1]), ACC[NQ - 1], 0, 0, 0);
+        ACC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                        \
+            __builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B[1]), ACC[1], 0, 0, 0);    \
+    if constexpr (NQ > 2)                                                                       \
+        ACC[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                        \
+            __builtin_bit_cast(half8, A), __builtin_bit_cast(half8, B[2]), ACC[2], 0, 0, 0);
 #define PS_MMA(A0, A1, B)                                                                       \
     PS_MMA1(acc_a, A0, B) PS_MMA1(acc_b, A1, B)                                                 \
     asm volatile("" : "+v"(acc_a[0]));
@@ -272,3 +281,4 @@ __global__ __launch_bounds__(256) void quantize_f16(const float* __restrict__ do
 }
 
 }  // namespace thr
+

@@ -67,7 +67,7 @@ class GpuIndex:
     SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
     F16_DIMS = (512, 768, 1024)
     AUTO_COPY_FRACTION = 0.10
-    F16_MAX_ROWS = 1 << 26       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
+    F16_MAX_ROWS = 1 << 25       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
 
     def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
