@@ -37,6 +37,25 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
                             None, None) == -1
 
 
+def test_host_side_planning_functions():
+    """Sizes and the query-tile choice are pure host arithmetic (no launch)."""
+    N = T._native
+    N.load()
+    # f16 copy scan: 64-query tiles, or 96 when the batch's tile count fills the CUs better
+    assert N.dense_f16_query_tile(768, True, 1024) == 64      # 16 tiles of 64 = one round
+    assert N.dense_f16_query_tile(768, True, 1536) == 96      # 16 tiles of 96 vs 24 of 64
+    assert N.dense_f16_query_tile(768, True, 3072) == 96
+    assert N.dense_f16_query_tile(1024, True, 1536) == 64     # 96 x 1024 halves do not fit LDS
+    assert N.dense_f16_query_tile(768, False, 1536) == 64     # in-flight rounding: transpose tiles
+    assert N.dense_f16_query_tile(1024, False, 1536) == 32
+    assert N.dense_f16_query_tile(640, True, 64) == 0         # no f16 kernel at that dim
+    lib = N.load()
+    assert lib.thr_dense_f16_copy_bytes(33, 768) == 64 * 768 * 2   # rows padded to tiles of 32
+    assert lib.thr_dense_rescue_workspace_bytes(1024, 100) == 1024 * 64 * 100 * 16
+    assert lib.thr_dense_f16_workspace_bytes(1_000_000, 768, 1536, 192) >= \
+        lib.thr_dense_f16_workspace_bytes(1_000_000, 768, 1024, 192)
+
+
 def test_no_cpu_fallback_in_the_product_package():
     """The product path must not import the oracle or fall back to CPU math."""
     pkg = os.path.join(ROOT, "triple-hybrid-rag_amd")
