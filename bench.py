@@ -125,7 +125,7 @@ def main():
     FLAVOURS = ("f16-inline", "f16", "f32")
     KERNEL = {"f32": f"dense_scan_mfma2<dim={args.dim},MODE_FILTER>",
               "f16": f"dense_scan_f16p<dim={args.dim},MODE_FILTER> (fragment-major f16 copy)",
-              "f16-inline": f"dense_scan_f16<dim={args.dim},MODE_FILTER,F32IN=1>"}
+              "f16-inline": f"dense_scan_f16<dim={args.dim},MODE_FILTER> (float32 rows rounded in flight)"}
 
     def set_flavour(name):
         """Switch the shortlist scan of the (already resident) index in place."""

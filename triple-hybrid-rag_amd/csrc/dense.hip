@@ -1277,7 +1277,7 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
 }
 
 // rows16 != nullptr: stream the fragment-major float16 copy (dense_scan_f16p); else stream the
-// float32 rows and round them in flight (dense_scan_f16<F32IN>)
+// float32 rows and round them in flight (dense_scan_f16)
 template <int MODE>
 static int launch_scan_f16(int dim, int nq, const float* rows32, const _Float16* rows16,
                            const float* inv_norm, int64_t n_docs,
@@ -1310,8 +1310,8 @@ static int launch_scan_f16(int dim, int nq, const float* rows32, const _Float16*
     }
 #define THR_H_INLINE(DIM, NQV)                                                                    \
     {                                                                                             \
-        if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV, true>), rows)                  \
-        else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV, true>), rows)                    \
+        if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV>), rows)                        \
+        else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV>), rows)                          \
     }
     const int key = dim * 10 + nq;
     if (packed) {

@@ -1,21 +1,20 @@
-// Shortlist scan on the f16 matrix cores (thr_dense_topk_f16), in two flavours:
-//   F32IN = false: streams a float16 COPY of the corpus (half the bytes per row);
-//   F32IN = true : streams the float32 rows themselves and rounds them to float16 in registers
-//                  on the way into the LDS transpose tile -- no second copy of the corpus.
+// Shortlist scan on the f16 matrix cores over the float32 rows themselves
+// (thr_dense_topk_f16 with docs16 == NULL): the rows are rounded to float16 in registers on the
+// way into the LDS transpose tile -- no second copy of the corpus.  (The flavour that streams a
+// float16 copy is dense_scan_f16p.hpp: fragment-major copy, no LDS transpose.)
 //
 // The float32 corpus stays the source of truth: every returned score is the float64
-// rescoring of float32 rows, and the top-k is certified with an error bound that now
-// also covers the quantisation of rows and queries (see select_rescore / DESIGN.md 4.1b):
+// rescoring of float32 rows, and the top-k is certified with an error bound that also covers
+// the quantisation of rows and queries (see select_rescore / DESIGN.md 4.1):
 //     |fp16-scan score - true cosine| <= ea*(1+eq) + eq + eps32        (relative to 1)
 //   ea = max over rows of ||d16 - d|| / ||d||   (measured at index build, thr_dense_quantize_f16)
 //   eq = ||q16 - q|| / ||q||                    (measured per query in kth_select)
 //   eps32 = fp32 accumulation bound of the MFMA chain
-// What the copy buys: half the HBM bytes per corpus pass, f16 MFMA at 16x the f32 rate, and a
-// query tile of 64 (96 KiB of LDS as f16) instead of 32 -- i.e. 4x fewer bytes per query.
 //
 // Kernel structure = dense_scan_mfma2 (coalesced loads -> register ring -> per-wave LDS
 // transpose tile -> fragment reads by inline asm with hand-counted lgkmcnt), with a stage =
-// 64 dims (the same 128 B per row) and ONE v_mfma_f32_32x32x16_f16 per 16-byte fragment pair.
+// 64 dims and ONE v_mfma_f32_32x32x16_f16 per 16-byte fragment pair; 64 queries per pass (96 KiB
+// of LDS as f16) at dim <= 768, 32 at dim 1024.
 #pragma once
 
 namespace thr {
@@ -34,13 +33,13 @@ __device__ __forceinline__ f32x4 pack_f16x8(f32x4 lo, f32x4 hi) {
     return __builtin_bit_cast(f32x4, v);
 }
 
-// NQ = query sub-tiles of 32 (1 or 2).  With F32IN a stage (64 dims of 32 rows) is 8 KiB of
-// float32: each lane loads float4 #c and #(8+c) of its row's 16 (two fully coalesced 128-byte
-// row segments per 8 lanes) and packs them into ONE 16-byte f16 chunk, i.e. chunk c of a stage
-// holds dims {4c..4c+3, 32+4c..32+4c+3}.  The query tile is laid out with the same permutation;
-// k is only a summation index, so the dot products are unchanged.  The register ring then holds
-// 2 stages instead of 4 (the same 16 KiB in flight per wave).
-template <int DIM, int MODE, bool nt_loads, int NQ, bool F32IN = false>
+// NQ = query sub-tiles of 32 (1 or 2).  A stage (64 dims of 32 rows) is 8 KiB of float32: each
+// lane loads float4 #c and #(8+c) of its row's 16 (two fully coalesced 128-byte row segments
+// per 8 lanes) and packs them into ONE 16-byte f16 chunk, i.e. chunk c of a stage holds dims
+// {4c..4c+3, 32+4c..32+4c+3}.  The query tile is laid out with the same permutation; k is only a
+// summation index, so the dot products are unchanged.  The register ring holds 2 stages (16 KiB
+// in flight per wave).
+template <int DIM, int MODE, bool nt_loads, int NQ>
 __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     const void* __restrict__ docs16, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
@@ -48,8 +47,8 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
     constexpr int QT = 32 * NQ;
     constexpr int CPR = DIM / 8;   // 16-byte chunks (8 halves) per row
-    constexpr int GPR = F32IN ? DIM / 4 : DIM / 8;  // 16-byte chunks per row in global memory
-    constexpr int GSTEP = F32IN ? 16 : 8;           // ... per stage
+    constexpr int GPR = DIM / 4;   // 16-byte chunks per float32 row in global memory
+    constexpr int GSTEP = 16;      // ... per stage
     constexpr int NG = DIM / 256;  // groups of 4 stages of 64 dims
     constexpr int QBITS = 32 - ROW_BITS_F16;
     static_assert(DIM % 256 == 0 && NG >= 2, "f16 scan needs dim % 256 == 0 and dim >= 512");
@@ -83,9 +82,9 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
         if (qg < n_queries) {
-            // dims of chunk c: 8c..8c+7, or (F32IN) the two float4 the row loader pairs up
-            const int d_lo = F32IN ? 64 * (c >> 3) + 4 * (c & 7) : 8 * c;
-            const int d_hi = F32IN ? d_lo + 32 : d_lo + 4;
+            // dims of chunk c: the two float4 the row loader pairs up
+            const int d_lo = 64 * (c >> 3) + 4 * (c & 7);
+            const int d_hi = d_lo + 32;
             const float* qsrc = queries + (int64_t)qg * DIM;
             const float4 lo = *reinterpret_cast<const float4*>(qsrc + d_lo);
             const float4 hi = *reinterpret_cast<const float4*>(qsrc + d_hi);
@@ -129,13 +128,12 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
 #define HS_LD(ptr) (nt_loads ? __builtin_nontemporal_load(&docs4[ptr]) : docs4[ptr])
 #define HS_LOAD1(dst, i, p)                                             \
     THR_PIN(p); dst[i] = HS_LD(p);                                      \
-    if constexpr (F32IN) dst[4 + i] = HS_LD(p + 8);                     \
+    dst[4 + i] = HS_LD(p + 8);                                          \
     p += GSTEP;
 #define HS_LOAD(dst) HS_LOAD1(dst, 0, p0) HS_LOAD1(dst, 1, p1) HS_LOAD1(dst, 2, p2) HS_LOAD1(dst, 3, p3)
 #define HS_STORE1(src, i, ws)                                           \
     THR_PIN(ws);                                                        \
-    if constexpr (F32IN) stage[ws] = pack_f16x8(src[i], src[4 + i]);    \
-    else stage[ws] = src[i];
+    stage[ws] = pack_f16x8(src[i], src[4 + i]);
 #define HS_STORE(src) HS_STORE1(src, 0, wslot0) HS_STORE1(src, 1, wslot1) HS_STORE1(src, 2, wslot2) HS_STORE1(src, 3, wslot3)
     // 1 + NQ LDS reads per quad: the row fragment and one query fragment per sub-tile.
     // qoff = chunk offset (in 16-byte units) of the stage's first chunk group (multiple of 16).
@@ -180,18 +178,13 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     f0.a = f1.a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NQ; ++s) f0.b[s] = f1.b[s] = f0.a;
-    constexpr int RW = F32IN ? 8 : 4;  // registers per ring slot
-    f32x4 ring0[RW], ring1[RW], ring2[RW], ring3[RW];
+    f32x4 ring0[8], ring1[8];  // 2 ring slots: 2 float4 per loader row of a stage
     int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
     int64_t t = wave_id;
     if (t < n_tiles) {
         p0 = load_off(t, 0); p1 = load_off(t, 1); p2 = load_off(t, 2); p3 = load_off(t, 3);
         HS_LOAD(ring0)
         HS_LOAD(ring1)
-        if constexpr (!F32IN) {
-            HS_LOAD(ring2)
-            HS_LOAD(ring3)
-        }
         HS_STORE(ring0)
         HS_LOAD(ring0)
         HS_READ(f0, 0, 0, 0, 0)
@@ -216,22 +209,13 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
         for (int g = 0; g < NG; ++g) {
             const int qb = 32 * g;                      // chunk offset of stages 4g, 4g+1
             const int qn = g + 1 < NG ? qb + 32 : 0;    // first chunks of the next group / tile
-            if constexpr (!F32IN) {
-                // ring of 4: the refill issued in stage u is stage 4g+u+5
-                HS_STAGE(0, ring1, qb, qb)
-                HS_STAGE(1, ring2, qb, qb + 16)
-                HS_STAGE(2, ring3, qb + 16, qb + 16)
-                if (g == NG - 2) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
-                HS_STAGE(3, ring0, qb + 16, qn)
-            } else {
-                // ring of 2: the refill issued in stage u is stage 4g+u+3 -- from u = 1 of the
-                // last group on, that is the head of the wave's next row tile
-                HS_STAGE(0, ring1, qb, qb)
-                if (g == NG - 1) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
-                HS_STAGE(1, ring0, qb, qb + 16)
-                HS_STAGE(2, ring1, qb + 16, qb + 16)
-                HS_STAGE(3, ring0, qb + 16, qn)
-            }
+            // ring of 2: the refill issued in stage u is stage 4g+u+3 -- from u = 1 of the
+            // last group on, that is the head of the wave's next row tile
+            HS_STAGE(0, ring1, qb, qb)
+            if (g == NG - 1) { p0 = on0; p1 = on1; p2 = on2; p3 = on3; }
+            HS_STAGE(1, ring0, qb, qb + 16)
+            HS_STAGE(2, ring1, qb + 16, qb + 16)
+            HS_STAGE(3, ring0, qb + 16, qn)
         }
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
