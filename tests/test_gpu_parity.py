@@ -394,6 +394,17 @@ def test_full_size_1m_dense(T):
     Se, Ie, _ = CO.dense_topk_exact(x, q[sub], 100, dnorm=idx.dnorm.cpu().numpy())
     for j, qi in enumerate(sub):
         assert np.array_equal(I[qi], Ie[j]) and np.array_equal(S[qi], Se[j])
+    # the bench batch (1536 queries = 16 tiles of 96 on the f16 copy scan): every shortlist
+    # flavour returns the same bits, and they are the oracle's fast path's
+    qb = synth.dense_queries(1536, d, n)
+    Sf, If = O.dense_topk_fast(x, qb, 100, dnorm=idx.dnorm.cpu().numpy())
+    Sf, If = np.stack(Sf), np.stack(If)
+    for mode in ("f16", "f16-inline", "f32"):
+        idx = T.GpuIndex().set_dense(x, shortlist=mode)
+        S, I, cnt, nres = idx.dense_search(dev(qb), 100)
+        assert nres == 0
+        assert np.array_equal(I.cpu().numpy(), If) and np.array_equal(S.cpu().numpy(), Sf), mode
+        del idx
 
 
 def test_dropin_retrieve_end_to_end(T):
