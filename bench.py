@@ -52,6 +52,10 @@ def parse():
                     help="queries per step (batch): 1536 = 16 tiles of 96 queries, one full round "
                          "of the 256 CUs for the default scan (1024 = 16 tiles of 64)")
     ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--doc-shards", type=int, default=0,
+                    help="N > 1: split the corpus into this many document shards (default N: the "
+                         "pure document-sharded layout); the N / doc-shards groups are replicas "
+                         "that serve different query batches (distributed.layout_2d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=1536)
     ap.add_argument("--probe-reps", type=int, default=5)
@@ -85,13 +89,21 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     # ---- inputs (deterministic, identical for every world size) ----
-    lo, hi = shard_range(args.docs, rank, world)
+    from triple_hybrid_rag_amd.distributed import layout_2d, replica_groups
+    doc_shards = args.doc_shards or world
+    shard, replica, _ = layout_2d(rank, world, doc_shards)
+    n_replicas = world // doc_shards
+    group = None
+    if world > 1 and n_replicas > 1:
+        group = replica_groups(world, doc_shards)[replica]
+    lo, hi = shard_range(args.docs, shard, doc_shards)
     t0 = time.time()
     docs = synth.dense_rows(lo, hi - lo, args.dim)
-    queries = synth.dense_queries(args.queries, args.dim, args.docs)
+    queries = synth.dense_queries(args.queries * n_replicas, args.dim, args.docs)
+    queries = np.ascontiguousarray(queries[replica::n_replicas])   # this replica's batch
     gen_s = time.time() - t0
     index = T.GpuIndex(doc_base=lo).set_dense(docs, shortlist=args.shortlist)
-    sharded = ShardedIndex(index)
+    sharded = ShardedIndex(index, group=group)
     qd = torch.from_numpy(queries).cuda()
     torch.cuda.synchronize()
 
@@ -187,7 +199,7 @@ def main():
     n_local = hi - lo
     primary = index.shortlist
     res, rescued, elapsed = measure()
-    qps = args.steps * args.queries / elapsed
+    qps = args.steps * args.queries * n_replicas / elapsed   # every replica serves its own batch
     roofline = probe_scan(primary)
 
     # ---- the other shortlist flavours, measured in the same run for comparison ----
@@ -199,7 +211,8 @@ def main():
                 continue
             set_flavour(name)
             r2, resc2, el2 = measure()
-            extras[name] = {"value": round(args.steps * args.queries / el2, 1), "unit": "queries/s",
+            extras[name] = {"value": round(args.steps * args.queries * n_replicas / el2, 1),
+                            "unit": "queries/s",
                             "ms_per_step": round(1e3 * el2 / args.steps, 3),
                             "rescued_queries": resc2, "roofline": probe_scan(name),
                             "fused_top10_identical_to_primary": bool(torch.equal(r2.ids, ids0))}
@@ -240,7 +253,8 @@ def main():
                                    f"top-{args.top_k} (BASELINE.json configs[1])",
                        "docs": args.docs, "dim": args.dim, "queries_per_step": args.queries,
                        "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": primary,
-                       "parallelism": f"doc-shard x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"doc-shard x{doc_shards}" + (f" x {n_replicas} replicas"
+                                       if n_replicas > 1 else "")) if world > 1 else "single GPU",
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -54,3 +54,49 @@ def test_two_rank_shard_gather_merge(tmp_path):
     cover = [shard_range(1_000_003, r, 8) for r in range(8)]
     assert cover[0][0] == 0 and cover[-1][1] == 1_000_003
     assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def _worker_2d(rank, world, port, n, d, k, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import thr_oracle as O
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import gather_topk, layout_2d, replica_groups, shard_range
+    doc_shards = 2
+    shard, replica, members = layout_2d(rank, world, doc_shards)
+    group = replica_groups(world, doc_shards)[replica]
+    assert rank in members and len(members) == doc_shards
+    lo, hi = shard_range(n, shard, doc_shards)
+    docs = synth.dense_rows(lo, hi - lo, d)
+    q = synth.dense_queries(6, d, n)[replica::world // doc_shards]   # this replica's queries
+    S, I = O.dense_topk_exact(docs, q, k, doc_id_base=lo)
+    Sg, Ig = gather_topk(torch.from_numpy(np.stack(S)), torch.from_numpy(np.stack(I)), group)
+    assert Sg.shape == (doc_shards, 3, k)
+    if shard == 0:
+        np.save(os.path.join(out_dir, f"S{replica}.npy"), Sg.numpy())
+        np.save(os.path.join(out_dir, f"I{replica}.npy"), Ig.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_doc_shards_times_replicas_layout(tmp_path):
+    """4 ranks = 2 document shards x 2 replicas: each replica answers its own queries from the
+    whole corpus; the exchange stays inside the replica."""
+    n, d, k, world = 2501, 64, 15, 4
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_2d, args=(world, port, n, d, k, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import thr_oracle as O
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import layout_2d
+    q = synth.dense_queries(6, d, n)
+    Se, Ie = O.dense_topk_exact(synth.dense_rows(0, n, d), q, k)
+    for replica in range(2):
+        Sg, Ig = np.load(tmp_path / f"S{replica}.npy"), np.load(tmp_path / f"I{replica}.npy")
+        for j, qi in enumerate(range(replica, 6, 2)):
+            ms, mi = O.topk_desc(Sg[:, j].ravel(), k, Ig[:, j].ravel())
+            assert np.array_equal(mi, Ie[qi]) and np.array_equal(ms, Se[qi])
+    assert layout_2d(5, 8, 2) == (1, 2, [4, 5]) and layout_2d(3, 8, 8) == (3, 0, list(range(8)))
+    with pytest.raises(ValueError):
+        layout_2d(0, 8, 3)

@@ -28,6 +28,26 @@ def shard_range(n_docs: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_docs, lo + per)
 
 
+def layout_2d(rank: int, world: int, doc_shards: int):
+    """Doc-shards x query-replicas layout of ``world`` ranks: the corpus is split into
+    ``doc_shards`` document ranges only as far as memory asks for (288 GB per MI355X hold
+    ~90M x 768 float32 rows), and the world // doc_shards groups of that many ranks are
+    REPLICAS that serve different query batches -- the per-batch costs that do not shrink with
+    the shard (threshold, shortlist, rescoring, exchange) are then paid once per replica instead
+    of once per GPU.  -> (shard index, replica index, ranks of this rank's replica).
+    doc_shards == world is the pure document-sharded layout (one replica)."""
+    if doc_shards < 1 or world % doc_shards:
+        raise ValueError("doc_shards must divide the world size")
+    replica, shard = divmod(rank, doc_shards)
+    return shard, replica, list(range(replica * doc_shards, (replica + 1) * doc_shards))
+
+
+def replica_groups(world: int, doc_shards: int):
+    """One process group per replica (every rank must create all of them, in this order)."""
+    return [dist.new_group(list(range(r * doc_shards, (r + 1) * doc_shards)))
+            for r in range(world // doc_shards)]
+
+
 def _as_tile(scores: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     """The [2, nq, k] int64 tile whose halves ``scores`` (as bit patterns) and ``ids`` are.  The
     kernels' outputs already are the two halves of one allocation (_native._alloc_out): then
