@@ -82,11 +82,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
+    # THR_BENCH_REHEARSAL=1: all ranks on cuda:0 over gloo -- exercises the N > 1 control flow
+    # (sharding, groups, exchange through the host, merge) on a one-GPU box; not a measurement
+    rehearsal = os.environ.get("THR_BENCH_REHEARSAL") == "1"
+    torch.cuda.set_device(0 if rehearsal else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     # ---- inputs (deterministic, identical for every world size) ----
     from triple_hybrid_rag_amd.distributed import layout_2d, replica_groups
@@ -129,7 +135,7 @@ def main():
         elapsed = time.perf_counter() - t0
         rescued = sum(int(c) for c in counters)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return res, rescued, elapsed

@@ -687,3 +687,29 @@ def test_dense_auto_shortlist_choice(T):
     x[5, 7] = -2e5
     idx = T.GpuIndex().set_dense(x)
     assert idx.shortlist == "f32" and idx.docs16 is None and idx.doc_rel_err == 0.0
+
+
+def test_bench_multi_rank_control_flow():
+    """bench.py --gpus 2 end to end on one GPU (THR_BENCH_REHEARSAL: both ranks on cuda:0, gloo in
+    place of RCCL): document sharding, exchange, merge and the single JSON line of rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, THR_BENCH_REHEARSAL="1")
+    port = 29800 + os.getpid() % 1000
+    for extra, label in (([], "doc-shard x2"), (["--doc-shards", "1"], "doc-shard x1 x 2 replicas")):
+        out = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+             "--gpus", "2", "--steps", "2", "--warmup", "1", "--docs", "40000", "--queries", "192",
+             "--no-extras", "--no-cpu-baseline"] + extra,
+            env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+        assert rec["config"]["parallelism"] == label and rec["config"]["rescued_queries"] == 0
+        port += 1
