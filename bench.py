@@ -109,6 +109,7 @@ def main():
     queries = np.ascontiguousarray(queries[replica::n_replicas])   # this replica's batch
     gen_s = time.time() - t0
     index = T.GpuIndex(doc_base=lo).set_dense(docs, shortlist=args.shortlist)
+    index.reserve(args.queries, 100)   # workspaces are part of the resident index, not of a step
     sharded = ShardedIndex(index, group=group)
     qd = torch.from_numpy(queries).cuda()
     torch.cuda.synchronize()

@@ -134,6 +134,20 @@ class GpuIndex:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def reserve(self, n_queries: int, k: int, kprime: Optional[int] = None) -> "GpuIndex":
+        """Allocate the dense workspaces for batches of ``n_queries`` up front (index set-up), so
+        that no search pays a device allocation."""
+        if self.shortlist != "f32":
+            kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 92)))
+            self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim, n_queries, kp))
+        else:
+            kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
+            self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, n_queries, kp))
+        need = N.dense_rescue_workspace_bytes(n_queries, k)
+        if self._ws_rescue is None or self._ws_rescue.numel() < need:
+            self._ws_rescue = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self
+
     def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
                      rescue: bool = True, sync: bool = True):
         """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
