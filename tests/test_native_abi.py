@@ -54,6 +54,12 @@ def test_host_side_planning_functions():
     assert lib.thr_dense_rescue_workspace_bytes(1024, 100) == 1024 * 64 * 100 * 16
     assert lib.thr_dense_f16_workspace_bytes(1_000_000, 768, 1536, 192) >= \
         lib.thr_dense_f16_workspace_bytes(1_000_000, 768, 1024, 192)
+    # the threshold sample grows with the corpus (n * 64 / 4096 rows, one float per query and
+    # row): a capped sample would let tens of thousands of rows per query through on a 10M-row
+    # shard and overflow every candidate list
+    grow = lib.thr_dense_f16_workspace_bytes(10_000_000, 768, 1536, 192) - \
+        lib.thr_dense_f16_workspace_bytes(1_000_000, 768, 1536, 192)
+    assert abs(grow - 1536 * (10_000_000 - 1_000_000) * 64 // 4096 * 4) < 64 * 1536 * 4 + 4096
 
 
 def test_no_cpu_fallback_in_the_product_package():

@@ -28,7 +28,7 @@ constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int CHUNK = 256;                 // floats per wave-wide float4 load (1 KiB)
 constexpr int MODE_ALL = 0, MODE_FILTER = 1;
 constexpr int CAND_CAP = 16384;            // candidates kept per query between K3 and K4
-constexpr int SAMPLE_TARGET = 32768;       // sample docs for the tau estimate
+constexpr int SAMPLE_MAX = 1 << 20;        // upper bound of the sample (rows) for the tau estimate
 constexpr int WBUF = 256;                  // per-wave LDS staging slots for passing rows
 constexpr int ROW_BITS = 27;               // tile-list entries pack (query-in-tile << 27 | row)
 constexpr uint32_t ROW_MASK = (1u << ROW_BITS) - 1;
@@ -1097,9 +1097,10 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     // at 64: the count of passing rows then spreads by ~1/8 of its mean (the tile share is 8
     // sigma away), and the sample pass + select cost a third of what ks = k' = 192 did.
     p.ksample = kprime < 64 ? kprime : 64;
+    // (the sample must grow with the corpus: a capped sample lets n / S * ks rows through, which
+    // overflows the candidate lists of every query on a 10M-row shard)
     int64_t target = n_docs * (int64_t)p.ksample / 4096;
-    const int64_t target_max = (int64_t)SAMPLE_TARGET * p.ksample / 128;
-    if (target > target_max) target = target_max;
+    if (target > SAMPLE_MAX) target = SAMPLE_MAX;
     if (target < 4 * (int64_t)p.ksample) target = 4 * (int64_t)p.ksample;
     int64_t sg = (target + p.unit - 1) / p.unit;
     if (sg > groups) sg = groups;
