@@ -45,7 +45,10 @@ enum {
 #define THR_FLAG_OVERFLOW 2u  /* candidate buffer overflowed (never certified)    */
 #define THR_FLAG_EXACT 4u     /* produced by the exhaustive float64 path          */
 
-#define THR_DENSE_MAX_K 256   /* k and k' (shortlist) upper bound */
+#define THR_DENSE_MAX_K 256   /* k and k' (shortlist) upper bound; the certificate needs a margin
+                               * k' - k of rows (28 for the fp32 scan, 92 for the f16 scans), so
+                               * beyond k ~ 200 queries increasingly take the exhaustive path
+                               * (still exact, much slower) */
 #define THR_BM25_MAX_TERMS 32
 #define THR_GRAPH_MAX_SEEDS 16
 #define THR_RRF_MAX_PER_CHANNEL 128
