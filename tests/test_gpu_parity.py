@@ -105,16 +105,21 @@ def test_dense_sampled_path(T, n, d):
 
 def test_dense_ties_duplicates_null_rows_need_rescue(T):
     x, rng = rand_docs(30000, 768, 9)
-    x[100:400] = x[99]          # 301 exact duplicates: top-100 is one giant tie
+    x[100:1700] = x[99]         # 1601 exact duplicates: top-100 is one giant tie
     x[5000] = 0                 # NULL embedding
     x[6000:6004] = 0
-    q = rng.standard_normal((6, 768)).astype(np.float32)
+    x[7000:7300] = x[6999]      # 301 duplicates: too many for the first 256-row band, but the
+    q = rng.standard_normal((6, 768)).astype(np.float32)   # 1024-row second chance holds them all
     q[0] = x[99] * 2.0
     q[1] = x[99] + 0.01 * q[1]
     q[2] = 0                    # zero query: every similarity is 0 -> first ids win
+    q[3] = x[6999] * 0.5
     idx = T.GpuIndex().set_dense(x)
     S, I, cnt, flg = T._native.dense_topk(idx.docs, idx.dnorm, idx.inv_norm, dev(q), 100, 128, 0)
-    assert (flg.cpu().numpy()[0] & 1) == 0, "a 301-way tie cannot be certified from 128 rows"
+    flg = flg.cpu().numpy()
+    assert (flg[0] & 1) == 0, "a 1601-way tie cannot be certified from a 1024-row band"
+    assert (flg[3] & 1) == 1, "a 301-way tie is settled exactly once every tied row is rescored"
+    assert list(I[3, :100].cpu().numpy()) == list(range(6999, 7099))
     S, I, cnt, nres = idx.dense_search(dev(q), 100)
     assert nres >= 1
     Se, Ie, cnte = CO.dense_topk_exact(x, q, 100)
@@ -618,12 +623,12 @@ def test_dense_edge_shapes_and_near_ties(T, shortlist):
     n, d = 40000, 768
     x, _ = rand_docs(n, d, 41)
     base = x[7].copy()
-    x[1000:1600] = base + 1e-6 * rng.standard_normal((600, d)).astype(np.float32)
-    x[2000:2050] = base + 1e-3 * rng.standard_normal((50, d)).astype(np.float32)
+    x[1000:2500] = base + 1e-6 * rng.standard_normal((1500, d)).astype(np.float32)
+    x[3000:3050] = base + 1e-3 * rng.standard_normal((50, d)).astype(np.float32)
     q = np.stack([base, base + 0.01 * x[8], x[9]]).astype(np.float32)
     idx = T.GpuIndex().set_dense(x, shortlist=shortlist)
     S, I, cnt, nres = idx.dense_search(dev(q), 100)
-    assert nres >= 1                      # the cloud cannot be certified from a 256-row shortlist
+    assert nres >= 1                      # 1500 rows in the band: more than the 1024-row second chance holds
     Se, Ie, cnte = CO.dense_topk_exact(x, q, 100)
     assert_topk_equal(S, I, cnt, Se, Ie, cnte, "near-ties")
     # unnormalised rows and queries (cosine must divide by both norms)

@@ -568,10 +568,17 @@ constexpr int SEL_THREADS = 256;
 constexpr int RS_ROWS = 32;        // rows per wave per batch
 constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
 constexpr int SEL_REG = 16;        // candidates per thread kept in registers
+constexpr int SEL_BIG_BAND = 1024; // band capacity of the second-chance launch
 static size_t select_lds_bytes(int dim) {
     const size_t stage = sizeof(float4) * 4 * RS_ROWS * RS_STRIDE, hist = sizeof(int) * CS_BINS;
     return sizeof(float) * dim + (stage > hist ? stage : hist);
 }
+// CAPB = rows the band may hold: 256 in the first launch; the queries it could not certify because
+// the band did not fit (score distributions squeezed into a narrow range: anisotropic embeddings
+// put hundreds of rows within the f16 error band of the k-th) get a second launch with 1024
+// (redo_flags != nullptr: workgroups of certified or overflowed queries exit at once) before the
+// exhaustive path is asked.
+template <int CAPB>
 __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
     const float* __restrict__ queries, const float* __restrict__ tau,
@@ -579,12 +586,13 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
     double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores,
     int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts,
-    uint32_t* __restrict__ out_flags) {
+    uint32_t* __restrict__ out_flags, const uint32_t* __restrict__ redo_flags) {
+    if (redo_flags && (redo_flags[blockIdx.x] & (THR_FLAG_CERTIFIED | THR_FLAG_OVERFLOW))) return;
     extern __shared__ float4 lds_sel[];  // [dim/4] query | hist (band) / 4 wave stage tiles (rescore)
     __shared__ int aux[8];
     __shared__ int bc[4];
-    __shared__ double s_s[THR_DENSE_MAX_K], o_s[THR_DENSE_MAX_K];
-    __shared__ int64_t s_id[THR_DENSE_MAX_K], o_id[THR_DENSE_MAX_K];
+    __shared__ double s_s[CAPB], o_s[CAPB];
+    __shared__ int64_t s_id[CAPB], o_id[CAPB];
     __shared__ int n_sel;
     __shared__ double s_qn, wsum[4];
     float* lds_qv = reinterpret_cast<float*>(lds_sel);
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     }
     for (int i = threadIdx.x; i < dim / 4; i += SEL_THREADS)
         lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
-    for (int i = threadIdx.x; i < THR_DENSE_MAX_K; i += SEL_THREADS) {
+    for (int i = threadIdx.x; i < CAPB; i += SEL_THREADS) {
         s_s[i] = o_s[i] = -INFINITY;
         s_id[i] = o_id[i] = INT64_MAX;
     }
@@ -664,20 +672,20 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         const float band = (float)((double)a_k - 2.5 * eps * qn_hi);
         const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
         if (band_lo > -INFINITY) {
-            // count and collect in one sweep; past THR_DENSE_MAX_K rows only the count matters
+            // count and collect in one sweep; past CAPB rows only the count matters
 #pragma unroll
             for (int u = 0; u < SEL_REG; ++u)
                 if (threadIdx.x + u * SEL_THREADS < n && mine[u].score >= band_lo) {
                     const int p = atomicAdd(&n_sel, 1);
-                    if (p < THR_DENSE_MAX_K) s_id[p] = mine[u].doc;
+                    if (p < CAPB) s_id[p] = mine[u].doc;
                 }
             for (int i = threadIdx.x + SEL_REG * SEL_THREADS; i < n; i += SEL_THREADS)
                 if (c[i].score >= band_lo) {
                     const int p = atomicAdd(&n_sel, 1);
-                    if (p < THR_DENSE_MAX_K) s_id[p] = c[i].doc;
+                    if (p < CAPB) s_id[p] = c[i].doc;
                 }
             __syncthreads();
-            if (n_sel <= THR_DENSE_MAX_K) {
+            if (n_sel <= CAPB) {
                 // rows outside the band: uncollected ones are below tau, collected ones below band_lo
                 floor32 = fmaxf(floor32, band_lo);
                 band_done = true;
@@ -769,20 +777,21 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         if (has_row) s_s[jm] = dot;  // the raw dot product for now
     }
     __syncthreads();
-    if (threadIdx.x < ns) {
-        const int64_t row = s_id[threadIdx.x];
-        const double qn = s_qn, dn = dnorm[row], dot = s_s[threadIdx.x];
+    for (int p = threadIdx.x; p < ns; p += SEL_THREADS) {
+        const int64_t row = s_id[p];
+        const double qn = s_qn, dn = dnorm[row], dot = s_s[p];
         double sim = -INFINITY;
         if (dn > 0.0) sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
-        s_s[threadIdx.x] = sim;
-        s_id[threadIdx.x] = sim == -INFINITY ? INT64_MAX : row + id_base;
+        s_s[p] = sim;
+        s_id[p] = sim == -INFINITY ? INT64_MAX : row + id_base;
     }
     __syncthreads();
     // rank sort: ids are distinct, so (score desc, id asc) is a strict order on the valid rows;
     // rows without an embedding all carry (-inf, INT64_MAX), which is what o_s/o_id hold already
-    if (threadIdx.x < ns && s_id[threadIdx.x] != INT64_MAX) {
-        const double ms = s_s[threadIdx.x];
-        const int64_t mi = s_id[threadIdx.x];
+    for (int p = threadIdx.x; p < ns; p += SEL_THREADS) {
+        const double ms = s_s[p];
+        const int64_t mi = s_id[p];
+        if (mi == INT64_MAX) continue;
         int rank = 0;
         for (int i = 0; i < ns; ++i) rank += better(s_s[i], s_id[i], ms, mi) ? 1 : 0;
         o_s[rank] = ms;
@@ -1416,10 +1425,16 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     if ((rc = launch_status())) return rc;
     const double u = 5.9604644775390625e-08;
     const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
-    hipLaunchKernelGGL(select_rescore, dim3(n_queries), dim3(SEL_THREADS), select_lds_bytes(dim), st,
-                       docs, dnorm, dim, id_base, queries, tau, cnt, cand, tcnt, p.tile_cap,
-                       p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores, out_ids,
-                       out_counts, out_flags);
+    hipLaunchKernelGGL(select_rescore<THR_DENSE_MAX_K>, dim3(n_queries), dim3(SEL_THREADS),
+                       select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
+                       tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
+                       out_ids, out_counts, out_flags, (const uint32_t*)nullptr);
+    if ((rc = launch_status())) return rc;
+    // second chance with a 1024-row band for the queries whose band did not fit 256 rows
+    hipLaunchKernelGGL(select_rescore<SEL_BIG_BAND>, dim3(n_queries), dim3(SEL_THREADS),
+                       select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
+                       tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
+                       out_ids, out_counts, out_flags, (const uint32_t*)out_flags);
     return launch_status();
 }
 
