@@ -678,6 +678,21 @@ def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
         assert [r.rrf_score for r in out] == [e["rrf_score"] for e in exp]
 
 
+def test_dense_rows_below_half_precision_range(T):
+    """Rows scaled into float16's subnormal range: "auto" answers with the fp32 scan, the f16
+    flavours refuse; results stay exact."""
+    x, rng = rand_docs(20000, 768, 12)
+    x *= 1e-6
+    q = (x[:5] + 1e-7 * rng.standard_normal((5, 768))).astype(np.float32)
+    idx = T.GpuIndex().set_dense(x)
+    assert idx.shortlist == "f32"
+    S, I, cnt, nres = idx.dense_search(dev(q), 20)
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 20)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "tiny rows")
+    with pytest.raises(T._native.NativeError, match="float16"):
+        T.GpuIndex().set_dense(x, shortlist="f16")
+
+
 def test_dense_auto_shortlist_choice(T):
     x, _ = rand_docs(3000, 768, 6)
     idx = T.GpuIndex().set_dense(x)

@@ -68,6 +68,7 @@ class GpuIndex:
     F16_DIMS = (512, 768, 1024)
     AUTO_COPY_FRACTION = 0.10
     F16_MAX_ROWS = 1 << 25       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
+    F16_MAX_REL_ERR = 2e-3       # ~8x the rounding error of rows in float16's normal range
 
     def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
@@ -95,10 +96,13 @@ class GpuIndex:
         if shortlist != "f32":
             self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
                                                                  keep_copy=shortlist == "f16")
-            if not np.isfinite(self.doc_rel_err):
+            # float16 holds the rows when no value overflows (|v| < 65504: else the measured error
+            # is +inf) and few underflow (rows scaled to ~1e-6 are all subnormals: the error bound
+            # would exceed F16_MAX_REL_ERR and no query could be certified)
+            if not np.isfinite(self.doc_rel_err) or self.doc_rel_err > self.F16_MAX_REL_ERR:
                 if not auto:
-                    raise N.NativeError("rows do not fit float16 (|value| >= 65504): use "
-                                        "shortlist='f32'")
+                    raise N.NativeError("rows do not fit float16 (values >= 65504 or mostly below "
+                                        "6e-5 in magnitude): use shortlist='f32'")
                 shortlist, self.docs16, self.doc_rel_err = "f32", None, 0.0
         self.shortlist = shortlist
         return self
