@@ -25,6 +25,14 @@ def load_golden(name):
         return json.load(f)
 
 
+def decode_array(obj):
+    """Inverse of make_golden.b64: {"dtype", "shape", "b64"} -> numpy array."""
+    import base64
+    import numpy as np
+    return np.frombuffer(base64.b64decode(obj["b64"]), dtype=np.dtype(obj["dtype"])).reshape(
+        obj["shape"]).copy()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

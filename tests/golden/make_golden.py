@@ -31,6 +31,8 @@ from voice_agent.retrieval import reranker as ref_rr  # noqa: E402
 from triple_hybrid_rag.config import RAGConfig  # noqa: E402
 from triple_hybrid_rag.core import fusion as ref_fusion  # noqa: E402
 from triple_hybrid_rag import types as ref_types  # noqa: E402
+from triple_hybrid_rag.core import embedder as ref_core_embedder  # noqa: E402
+from voice_agent.tools import crm_knowledge as ref_crm  # noqa: E402
 
 
 def dump(name, obj):
@@ -444,6 +446,180 @@ def gen_planner(rng):
     return out
 
 
+def b64(arr):
+    """An array as data: little-endian bytes, base64 (tests/conftest.py decode_array)."""
+    import base64
+    import numpy as np
+    a = np.ascontiguousarray(arr)
+    return {"dtype": a.dtype.newbyteorder("<").str, "shape": list(a.shape),
+            "b64": base64.b64encode(a.astype(a.dtype.newbyteorder("<")).tobytes()).decode()}
+
+
+class _KBQuery:
+    """knowledge_base_chunks query builder of the fallback scorer (hybrid_search.py:268-284)."""
+
+    def __init__(self, rows, log):
+        self.rows, self.log, self.not_ = rows, log, self
+
+    def select(self, cols):
+        self.log.append(["select", cols])
+        return self
+
+    def eq(self, col, val):
+        self.log.append(["eq", col, val])
+        self.rows = [r for r in self.rows if r.get(col) == val]
+        return self
+
+    def is_(self, col, val):          # reached through `.not_.is_(col, "null")`
+        self.log.append(["not_is", col, val])
+        self.rows = [r for r in self.rows if r.get(col) is not None]
+        return self
+
+    def limit(self, n):
+        self.log.append(["limit", n])
+        self.rows = self.rows[:n]
+        return self
+
+    def execute(self):
+        return _Exec(self.rows)
+
+
+class _KBClient:
+    def __init__(self, rows):
+        self.rows, self.log = rows, []
+
+    def table(self, name):
+        self.log.append(["table", name])
+        return _KBQuery(list(self.rows), self.log)
+
+
+def gen_dense():
+    """Pins the dense score: the reference's two Python cosine scorers, run on
+    float32-valued vectors.  (i) MultimodalEmbedder.cosine_similarity (core/embedder.py:316-331)
+    for every (query, row) pair of a [24] x [120] set with zero, unnormalised and duplicate
+    vectors; (ii) HybridSearcher._vector_search_fallback (hybrid_search.py:260-320) over a fake
+    knowledge_base_chunks table holding the unit-normalised rows (NULL embedding for zero rows):
+    returned ids, order and similarity scores."""
+    import numpy as np
+    nrng = np.random.default_rng(20260204)
+    n, nq, d = 120, 24, 512
+    rows = nrng.standard_normal((n, d)).astype(np.float32)
+    rows *= nrng.choice([0.01, 1.0, 30.0], size=(n, 1)).astype(np.float32)
+    rows[5] = 0
+    rows[17] = 0
+    rows[40:44] = rows[39]                      # exact duplicates: ties
+    rows[60] = rows[59] * np.float32(2.0)       # same direction, other norm
+    rows[70] = rows[69] + np.float32(1e-4) * nrng.standard_normal(d).astype(np.float32)
+    q = nrng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = rows[39]
+    q[1] = rows[59] * np.float32(0.25)
+    q[2] = 0
+    q[3] = rows[69]
+    q[4:12] = rows[nrng.integers(0, n, 8)] + np.float32(0.5) * q[4:12]
+    emb = ref_core_embedder.MultimodalEmbedder.__new__(ref_core_embedder.MultimodalEmbedder)
+    cos = [[emb.cosine_similarity(q[i].tolist(), rows[j].tolist()) for j in range(n)]
+           for i in range(nq)]
+    # (ii) the table stores what a1 produces: float32 L2-normalised rows (rag2/embedder.py:31-37)
+    unit = np.array([ref_embedder.normalize_l2(r.tolist()) for r in rows], dtype=np.float32)
+    qunit = np.array([ref_embedder.normalize_l2(v.tolist()) for v in q], dtype=np.float32)
+    table = [{"id": f"c{j}", "org_id": "org", "content": f"text {j}", "modality": "text",
+              "source_document": "doc", "page": 1 + j % 7, "chunk_index": j,
+              "category": "faq" if j % 3 == 0 else "pricing",
+              "vector_embedding": unit[j].tolist() if rows[j].any() else None}
+             for j in range(n)]
+    searcher = ref_hs.HybridSearcher.__new__(ref_hs.HybridSearcher)
+    searcher.org_id = "org"
+    searcher.config = ref_hs.SearchConfig(top_k_retrieve=60)
+    fallback = []
+    for i in range(nq):
+        for category in (None, "faq") if i < 6 else (None,):
+            client = _KBClient(table)
+            searcher._supabase = client
+            res = asyncio.run(searcher._vector_search_fallback(qunit[i].tolist(), category))
+            fallback.append({"query": i, "category": category, "top_k_retrieve": 60,
+                             "calls": client.log,
+                             "out": [{"chunk_id": r.chunk_id, "similarity_score": r.similarity_score,
+                                      "retrieval_method": r.retrieval_method} for r in res]})
+    return {"dim": d, "rows": b64(rows), "queries": b64(q), "cosine_similarity": cos,
+            "unit_rows": b64(unit), "unit_queries": b64(qunit),
+            "null_rows": [j for j in range(n) if not rows[j].any()],
+            "categories": [t["category"] for t in table], "fallback": fallback}
+
+
+def gen_tool(rng):
+    """_search_knowledge_base_rag2 (tools/crm_knowledge.py:69-182) over a fake retriever: the dict
+    schema, rounding, falsy-score handling, refusal mapping and millisecond timings."""
+    C = ref_retrieval.RetrievalCandidate
+    cases = []
+    fixed_score = [None, 0.0, 0.85, 0.01639344262295082, 0.92, 0.00004, 1.0]
+    for ci in range(14):
+        refused = ci in (3, 9)
+        n = 0 if ci == 5 else rng.randint(1, 6)
+        ctxs = []
+        for j in range(n):
+            ctxs.append(dict(
+                child_id=f"child-{ci}-{j}", parent_id=f"parent-{ci}-{j // 2}",
+                document_id=f"doc-{ci}", text=f"child text {j}", page=rng.randint(1, 30),
+                modality=rng.choice(["text", "table", "image"]),
+                lexical_rank=rng.choice([None, 1, 2, 17]), semantic_rank=rng.choice([None, 1, 3, 99]),
+                graph_rank=rng.choice([None, 1, 4]),
+                rrf_score=rng.choice(fixed_score[1:] + [round(rng.random() * 0.05, 6)]),
+                parent_text=rng.choice([None, "", f"parent text {j}"]),
+                section_heading=rng.choice([None, "", "Section Title"]),
+                rerank_score=rng.choice(fixed_score + [rng.random()])))
+        res = dict(success=True, contexts=ctxs,
+                   max_rerank_score=rng.choice([0.0, 0.92, rng.random()]),
+                   refused=refused,
+                   refusal_reason="Max score 0.01 below threshold 0.6" if refused else None,
+                   timings={"planning": rng.random() * 0.2, "retrieval": rng.random(),
+                            "fusion": 1.23456e-4, "total": 0.33335})
+        call = dict(query=rng.choice(["What is the policy?", "preço do plano", ""]),
+                    category=rng.choice([None, "faq", "pricing"]), limit=rng.choice([1, 5, 10]),
+                    org_id=rng.choice([None, "org-explicit"]))
+        seen = {}
+
+        class FakeRetriever:
+            def __init__(self, org_id, graph_enabled=False, _seen=seen):
+                _seen["init"] = {"org_id": org_id, "graph_enabled": graph_enabled}
+
+            async def retrieve(self, query, collection=None, top_k=None, _seen=seen, _res=res):
+                _seen["retrieve"] = {"query": query, "collection": collection, "top_k": top_k}
+                return ref_retrieval.RetrievalResult(
+                    success=_res["success"], contexts=[C(**c) for c in _res["contexts"]],
+                    max_rerank_score=_res["max_rerank_score"], refused=_res["refused"],
+                    refusal_reason=_res["refusal_reason"], timings=dict(_res["timings"]))
+
+        class FakeDB:
+            def table(self, name, _seen=seen):
+                _seen.setdefault("tables", []).append(name)
+                return self
+
+            def select(self, *_a):
+                return self
+
+            def limit(self, _n):
+                return self
+
+            def execute(self):
+                return _Exec([{"org_id": "org-123", "id": "org-first"}])
+
+        keep = (ref_retrieval.RAG2Retriever, ref_crm.get_supabase_client,
+                SETTINGS.rag2_graph_enabled)
+        ref_retrieval.RAG2Retriever = FakeRetriever
+        ref_crm.get_supabase_client = lambda: FakeDB()
+        graph_flag = ci % 2 == 0
+        object.__setattr__(SETTINGS, "rag2_graph_enabled", graph_flag)
+        try:
+            out = ref_crm._search_knowledge_base_rag2(call["query"], call["category"],
+                                                      call["limit"], call["org_id"])
+        finally:
+            ref_retrieval.RAG2Retriever, ref_crm.get_supabase_client = keep[0], keep[1]
+            object.__setattr__(SETTINGS, "rag2_graph_enabled", keep[2])
+        cases.append({"call": call, "result": res, "rag2_graph_enabled": graph_flag,
+                      "seen": seen, "out": out})
+    return cases
+
+
 def main():
     rng = random.Random(20260130)
     dump("embed_postproc.json", gen_embed(rng))
@@ -454,6 +630,8 @@ def main():
     dump("legacy_rerank.json", gen_legacy(rng))
     dump("standalone_fusion.json", gen_standalone(rng))
     dump("simple_planner.json", gen_planner(rng))
+    dump("dense_cosine.json", gen_dense())
+    dump("tool_layer.json", gen_tool(random.Random(20260205)))
     dump("defaults.json", {
         "settings": {k: getattr(SETTINGS, k) for k in (
             "rag2_enabled", "rag2_graph_enabled", "rag2_rerank_enabled", "rag2_denoise_enabled",

@@ -128,6 +128,91 @@ def test_dense_ties_duplicates_null_rows_need_rescue(T):
     assert 5000 not in set(I.cpu().numpy().ravel())
 
 
+@pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
+def test_dense_candidate_list_overflow_goes_to_rescue(T, shortlist):
+    """Forces THR_FLAG_OVERFLOW: 60 queries sit on a 20 000-row duplicate cluster, so each of them
+    has more rows >= tau than CAND_CAP (16 384) and every query tile's shared list (qtile * 8192
+    entries: 32 / 64 / 96 queries per tile) overflows while the ordinary queries of the same tile
+    have short lists.  The workspace is prefilled with 0xFF: round 1's select_rescore read all
+    CAND_CAP slots of such an ordinary query and used the stale words as row indices (the abort of
+    gpurun_out/t1.log); it must read only the slots that were written.  After thr_dense_rescue the
+    batch equals the oracle."""
+    n, d, nq, ndup = 60000, 768, 96, 20000
+    x, rng = rand_docs(n, d, 17)
+    x[30000:30000 + ndup] = x[29999]
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[:60] = x[29999] + 1e-3 * q[:60]
+    q[60:80] = x[rng.integers(0, 29999, 20)] + 0.5 * q[60:80]
+    idx = T.GpuIndex().set_dense(x, shortlist=shortlist)
+    idx.reserve(nq, 100)
+    idx._ws.fill_(0xFF)
+    qd = dev(q)
+    if shortlist == "f32":
+        S, I, cnt, flg = T._native.dense_topk(idx.docs, idx.dnorm, idx.inv_norm, qd, 100, 128, 0, idx._ws)
+    else:
+        S, I, cnt, flg = T._native.dense_topk_f16(idx.docs, idx.docs16, idx.doc_rel_err, idx.dnorm,
+                                                  idx.inv_norm, qd, 100, 192, 0, idx._ws)
+    flags = flg.cpu().numpy()
+    assert np.all(flags[:60] & T._native.THR_FLAG_OVERFLOW), "cluster queries overflow CAND_CAP"
+    assert np.all((flags[:60] & 1) == 0)
+    assert np.any(flags[60:] & T._native.THR_FLAG_OVERFLOW), "their tile's list overflowed too"
+    assert np.all((flags[60:][(flags[60:] & T._native.THR_FLAG_OVERFLOW) != 0] & 1) == 0)
+    idx._ws.fill_(0xFF)
+    S, I, cnt, nres = idx.dense_search(qd, 100)
+    assert nres >= 60
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 100)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "dense-overflow")
+    assert list(I[0, :100].cpu().numpy()) == list(range(29999, 30099))
+
+
+@pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
+def test_dense_matches_reference_python_cosine(T, golden, shortlist):
+    """a2 pinned by the reference's own Python (tests/golden/dense_cosine.json, generated from
+    MultimodalEmbedder.cosine_similarity, core/embedder.py:316-331, and
+    HybridSearcher._vector_search_fallback, hybrid_search.py:260-320): the same rows and queries
+    through thr_dense_topk / thr_dense_topk_f16.  Scores within 1e-5 (north star); identical
+    order wherever the reference's own scores are more than 1e-5 apart."""
+    from conftest import decode_array
+    g = golden("dense_cosine.json")
+    rows, q = decode_array(g["rows"]), decode_array(g["queries"])
+    ref = np.array(g["cosine_similarity"], dtype=np.float64)
+    null = set(g["null_rows"])
+    n = rows.shape[0]
+    idx = T.GpuIndex().set_dense(rows, shortlist=shortlist)
+    S, I, cnt, _ = idx.dense_search(dev(q), 100)
+    S, I, cnt = S.cpu().numpy(), I.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(q.shape[0]):
+        c = int(cnt[i])
+        assert c == 100 and not (set(I[i, :c].tolist()) & null)
+        assert np.max(np.abs(S[i, :c] - ref[i][I[i, :c]])) < 1e-5
+        if not q[i].any():
+            continue
+        live = np.array([j for j in range(n) if j not in null])
+        order = live[np.lexsort((live, -ref[i][live]))][:100]    # the reference's scores, our tie rule
+        sep = np.abs(np.diff(ref[i][order])) > 1e-5
+        for a in range(100):
+            if (a == 0 or sep[a - 1]) and (a == 99 or sep[a]):
+                assert I[i, a] == order[a]
+    # the fallback scorer's table: unit rows, NULL embeddings, optional category filter
+    unit, qunit = decode_array(g["unit_rows"]), decode_array(g["unit_queries"])
+    unit[sorted(null)] = 0                      # NULL embedding = zero row = excluded
+    idx = T.GpuIndex().set_dense(unit, shortlist=shortlist)
+    S, I, cnt, _ = idx.dense_search(dev(qunit), 60)
+    S, I = S.cpu().numpy(), I.cpu().numpy()
+    for c in g["fallback"]:
+        if c["category"] is not None or not qunit[c["query"]].any():
+            continue
+        ref_ids = [int(o["chunk_id"][1:]) for o in c["out"]]
+        ref_s = np.array([o["similarity_score"] for o in c["out"]])
+        got = I[c["query"], :60].tolist()
+        assert np.max(np.abs(S[c["query"], :60] - ref_s)) < 1e-5
+        gaps = np.abs(np.diff(ref_s))
+        for a in range(60):
+            if (a == 0 or gaps[a - 1] > 1e-5) and (a == 59 or gaps[a] > 1e-5):
+                assert got[a] == ref_ids[a]
+        assert sorted(got) == sorted(ref_ids) or np.min(gaps[58:]) <= 1e-5
+
+
 def test_dense_exact_path_alone(T):
     x, rng = rand_docs(20000, 256, 21)
     q = rng.standard_normal((9, 256)).astype(np.float32)

@@ -332,3 +332,57 @@ def test_legacy_hybrid_searcher_flow():
     assert out[1].similarity_score == 0.7 and out[1].bm25_score == 2.0 and out[0].page == 1
     only = asyncio.run(HybridSearcher("org", Emb(), SearchConfig(use_bm25=False))._with(be).search("q", source_document="docA"))
     assert [r.chunk_id for r in only] == ["k1", "k3"] and only[0].retrieval_method == "vector"
+
+
+def test_tool_layer_matches_reference(golden, settings_guard, monkeypatch):
+    """8f.2: _search_knowledge_base_rag2 against the reference's own function run over a fake
+    retriever (tests/golden/tool_layer.json <- tools/crm_knowledge.py:69-182): constructor and
+    retrieve() arguments, tenant discovery, dict schema, rounding of falsy scores, refusal
+    mapping, millisecond timings.  Known answers of tests/test_rag2_tool_connection.py:78-330
+    (chunk_id / parent_id / rounding / refusal keys) are covered by the same cases."""
+    from triple_hybrid_rag_amd.rag2.retrieval import RetrievalResult
+    from triple_hybrid_rag_amd.tools import crm_knowledge as crm
+    for c in golden("tool_layer.json"):
+        seen = {}
+
+        class FakeRetriever:
+            def __init__(self, org_id, graph_enabled=False):
+                seen["init"] = {"org_id": org_id, "graph_enabled": graph_enabled}
+
+            async def retrieve(self, query, collection=None, top_k=None, _r=c["result"]):
+                seen["retrieve"] = {"query": query, "collection": collection, "top_k": top_k}
+                return RetrievalResult(success=_r["success"],
+                                       contexts=[RetrievalCandidate(**x) for x in _r["contexts"]],
+                                       max_rerank_score=_r["max_rerank_score"], refused=_r["refused"],
+                                       refusal_reason=_r["refusal_reason"], timings=dict(_r["timings"]))
+
+        class FakeDB:
+            def table(self, name):
+                seen.setdefault("tables", []).append(name)
+                return self
+
+            def select(self, *_a):
+                return self
+
+            def limit(self, _n):
+                return self
+
+            def execute(self):
+                return _Reply([{"org_id": "org-123", "id": "org-first"}])
+
+        monkeypatch.setattr(crm, "RAG2Retriever", FakeRetriever)
+        monkeypatch.setattr(crm, "get_supabase_client", lambda: FakeDB())
+        SETTINGS.rag2_graph_enabled = c["rag2_graph_enabled"]
+        call = c["call"]
+        out = crm._search_knowledge_base_rag2(call["query"], call["category"], call["limit"],
+                                              call["org_id"])
+        assert out == c["out"]
+        assert seen == c["seen"]
+    # the dispatcher: RAG 2.0 when enabled, never raises into the agent
+    SETTINGS.rag2_enabled = True
+    c = golden("tool_layer.json")[0]
+    assert crm.search_knowledge_base(c["call"]["query"], c["call"]["category"],
+                                     c["call"]["limit"])["search_type"] == "rag2_triple_hybrid"
+    monkeypatch.setattr(crm, "get_supabase_client", lambda: (_ for _ in ()).throw(RuntimeError("db down")))
+    err = crm.search_knowledge_base("q", "faq")
+    assert err == {"error": "Database error: db down", "query": "q", "category": "faq"}

@@ -238,6 +238,11 @@ class GpuIndexClient:
         if name == "rag_parent_chunks":
             return _TableQuery(lambda ids: [dict(self.store.parents[p]) for p in ids
                                             if p in self.store.parents])
+        # tenant discovery of the tool layer (tools/crm_knowledge.py:89-101 in the reference)
+        if name == "rag_documents":
+            return _TableQuery(lambda _ids: [{"org_id": self.org_id}] if self.org_id else [])
+        if name == "organizations":
+            return _TableQuery(lambda _ids: [{"id": self.org_id}] if self.org_id else [])
         raise ValueError(f"table {name!r} is not served by the GPU index")
 
     # --------------------------------------------------------------- graph

@@ -608,7 +608,11 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const Cand* c = cand + (int64_t)q * CAND_CAP;
     const int cnt = cand_cnt[q];
     const bool overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
-    const int n = overflow ? CAND_CAP : cnt;
+    // Only slots [0, min(cnt, CAND_CAP)) were written.  (Round 1 read all CAND_CAP slots whenever
+    // the TILE list had overflowed, even for a query of that tile with few candidates of its
+    // own: stale workspace words became row indices -> out-of-bounds gathers, the rc 134 abort
+    // of gpurun_out/t1.log.  An overflowed query is never certified; thr_dense_rescue redoes it.)
+    const int n = cnt < CAND_CAP ? cnt : CAND_CAP;
 
     // candidates this thread keeps in registers (loads in flight while the query is staged)
     Cand mine[SEL_REG];
