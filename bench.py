@@ -48,16 +48,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--queries", type=int, default=1536,
-                    help="queries per step (batch): 1536 = 16 tiles of 96 queries, one full round "
-                         "of the 256 CUs for the default scan (1024 = 16 tiles of 64)")
+    ap.add_argument("--queries", type=int, default=2048,
+                    help="queries per step (batch): 2048 = 8 workgroup tiles of 256 queries x 4 "
+                         "row slices per XCD, one full round of the 256 CUs for the default scan")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--doc-shards", type=int, default=0,
                     help="N > 1: split the corpus into this many document shards (default N: the "
                          "pure document-sharded layout); the N / doc-shards groups are replicas "
                          "that serve different query batches (distributed.layout_2d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=1536)
+    ap.add_argument("--cpu-queries", type=int, default=2048)
     ap.add_argument("--probe-reps", type=int, default=5)
     ap.add_argument("--no-extras", "--no-f16-extra", dest="no_extras", action="store_true",
                     help="skip the measurements of the other shortlist flavours reported next to "
@@ -143,7 +143,8 @@ def main():
 
     FLAVOURS = ("f16-inline", "f16", "f32")
     KERNEL = {"f32": f"dense_scan_mfma2<dim={args.dim},MODE_FILTER>",
-              "f16": f"dense_scan_f16p<dim={args.dim},MODE_FILTER> (fragment-major f16 copy)",
+              "f16": f"dense_scan_f16q{'s' if args.dim <= 768 else ''}<dim={args.dim},MODE_FILTER> "
+                     "(queries in registers, fragment-major f16 rows through LDS-DMA)",
               "f16-inline": f"dense_scan_f16<dim={args.dim},MODE_FILTER> (float32 rows rounded in flight)"}
 
     def set_flavour(name):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 2
+#define THR_ABI_VERSION 3
 
 typedef void *thr_stream_t;
 
@@ -112,26 +112,27 @@ int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int
                      int32_t *n_rescued, void *workspace, size_t workspace_bytes,
                      thr_stream_t stream);
 
-/* Shortlist scan on the f16 matrix cores (64 or 96 queries per pass; < 2^25 rows per shard).  The float32 corpus stays the
+/* Shortlist scan on the f16 matrix cores (< 2^25 rows per shard).  The float32 corpus stays the
  * source of truth: scores are the same float64 rescoring of float32 rows, and the certificate's
- * error bound additionally covers row quantisation (doc_rel_err = max_d ||d16-d||/||d||,
- * measured by thr_dense_quantize_f16 into *max_rel_err, a DEVICE float) and query quantisation
- * (measured per query on the device).  Two flavours:
- *   docs16 != NULL: the scan streams a float16 COPY of the rows written by
- *                   thr_dense_quantize_f16.  The copy is an opaque FRAGMENT-MAJOR image of
- *                   thr_dense_f16_copy_bytes(n_docs, dim) bytes (rows padded to a multiple of 32):
- *                   [row tile of 32][stage of 64 dims][16-dim quad][lane = r + 32 h][8 halves],
- *                   the register image of the v_mfma_f32_32x32x16_f16 row operand, so the scan
- *                   loads its fragments with coalesced 1 KiB loads and the rows never pass
- *                   through LDS;
+ * error bound additionally covers row quantisation (doc_rel_err, measured by
+ * thr_dense_quantize_f16 into *max_rel_err, a DEVICE float) and query quantisation (measured per
+ * query on the device).  Two flavours:
+ *   docs16 != NULL: the scan streams a float16 COPY written by thr_dense_quantize_f16: an opaque
+ *                   FRAGMENT-MAJOR image of thr_dense_f16_copy_bytes(n_docs, dim) bytes,
+ *                   [row tile of 32][k-step of 16 dims][lane = r + 32 h][8 halves] = the register
+ *                   image of the v_mfma_f32_32x32x16_f16 row operand, holding the NORMALISED rows
+ *                   d/||d|| (NaN for rows without an embedding and for the padding of the last
+ *                   tile; doc_rel_err = max_d ||fp16(d/||d||) - d/||d|| ||, any value range).
+ *                   Row tiles reach LDS by LDS-DMA, once per CU; each wave keeps 32 queries in
+ *                   registers as the other operand (256 queries per CU, 128 at dim 1024);
  *   docs16 == NULL: the scan streams the float32 rows and rounds them to float16 in registers
  *                   (no second copy; thr_dense_quantize_f16 with docs16 == NULL only measures
- *                   doc_rel_err; 32 queries per pass at dim 1024).
- * dim in {512, 768, 1024}; |values| must be < 65504 (doc_rel_err is +inf otherwise and
- * thr_dense_topk_f16 rejects it). */
+ *                   doc_rel_err = max_d ||fp16(d) - d|| / ||d||, +inf when a value leaves the
+ *                   float16 range, which thr_dense_topk_f16 rejects; 64 queries per pass, 32 at
+ *                   dim 1024).
+ * dim in {512, 768, 1024}. */
 size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim);
-/* queries per row pass the f16 scan uses for a batch of n_queries (64, or 96 when that fills the
- * CUs better; 32 for the in-flight-rounding flavour at dim 1024) */
+/* queries per workgroup (= per pass over a row slice) of the f16 scan */
 int thr_dense_f16_query_tile(int dim, int packed /* docs16 != NULL */, int n_queries);
 int thr_dense_quantize_f16(const float *docs, int64_t n_docs, int dim,
                            uint16_t *docs16 /* thr_dense_f16_copy_bytes(...) bytes, or NULL */,
@@ -147,6 +148,16 @@ int thr_dense_scan_probe_f16(const float *docs, const uint16_t *docs16 /* or NUL
                              const float *inv_norm, int64_t n_docs, int dim, const float *queries,
                              int n_queries, void *workspace, size_t workspace_bytes,
                              thr_stream_t stream);
+
+/* Diagnostic build of the float16-copy scan (same launch as thr_dense_scan_probe_f16, on the
+ * workspace of the last thr_dense_topk_f16): every wave sums s_memtime deltas around the phases
+ * of its tile loop into stamps[wave * 8 + {0 wait for own DMA pieces, 1 barrier, 2 DMA issue,
+ * 3 k-loop, 4 emit, 5 tiles, 6 whole loop, 7 HW_ID}] (device, uint64).  stamps == NULL: only
+ * *h_n_waves (host) is set, to size the buffer.  Not a timing: the stamps drain the wave's
+ * queues; it says where the time goes (profiles/README.md). */
+int thr_dense_scan_stamps_f16(const uint16_t *docs16, int64_t n_docs, int dim, int n_queries,
+                              void *workspace, size_t workspace_bytes,
+                              unsigned long long *stamps, int *h_n_waves, thr_stream_t stream);
 
 /* Timing/roofline probe: ONLY the streaming pass-1 kernel of thr_dense_topk
  * (threshold filter against ``tau``), for ``n_tiles`` query tiles. */

@@ -23,12 +23,12 @@ FLAVOURS = ("f16-inline", "f16", "f32")
 KERNEL_TAG = {"f32": "dense_scan_mfma2", "f16": "dense_scan_f16p", "f16-inline": "dense_scan_f16<"}
 
 
-def run(flavour):
+def run(flavour, nq=NQ):
     import torch
     import triple_hybrid_rag_amd as T
     from triple_hybrid_rag_amd import synth
     x = torch.from_numpy(synth.dense_rows(0, N_DOCS, DIM)).cuda()
-    q = torch.from_numpy(synth.dense_queries(NQ, DIM, N_DOCS)).cuda()
+    q = torch.from_numpy(synth.dense_queries(nq, DIM, N_DOCS)).cuda()
     idx = T.GpuIndex().set_dense(x, shortlist=flavour)
     idx.dense_search(q, 100, rescue=False)       # sets tau in the workspace
     for _ in range(3):
@@ -117,6 +117,6 @@ def parse(d, out_path):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(sys.argv[2])
+        run(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else NQ)
     else:
         parse(sys.argv[2], sys.argv[3])

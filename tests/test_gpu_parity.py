@@ -590,18 +590,24 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
     q[5] = 0
     idx = T.GpuIndex(doc_base=123).set_dense(x, shortlist=mode)
     assert 0 < idx.doc_rel_err < 6e-4        # ~2^-12/sqrt(3) typical, 2^-11 worst case
-    x16 = x.astype(np.float16)
+    nz = x.any(axis=1)
     if mode == "f16":
-        # the copy is fragment-major: [tile of 32 rows][stage of 64 dims][quad][h][r][8 halves]
+        # the copy is fragment-major: [tile of 32 rows][k-step of 16 dims][h][r][8 halves]; it
+        # holds the NORMALISED rows, NaN for rows without an embedding and for the tile padding
         img = idx.docs16.cpu().numpy()
         tiles = img.shape[0] // 32
-        rows = img.reshape(tiles, d // 64, 4, 2, 32, 8).transpose(0, 4, 1, 2, 3, 5).reshape(tiles * 32, d)
-        assert np.array_equal(rows[:n], x16) and not rows[n:].any()
+        rows = img.reshape(tiles, d // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(tiles * 32, d)
+        unit = x.astype(np.float64) / np.maximum(np.linalg.norm(x.astype(np.float64), axis=1), 1e-300)[:, None]
+        exp16 = unit.astype(np.float32).astype(np.float16)
+        assert np.isnan(rows[n:]).all() and np.isnan(rows[:n][~nz]).all()
+        diff = np.abs(rows[:n][nz].astype(np.float32) - exp16[nz].astype(np.float32))
+        assert np.count_nonzero(diff) <= 1e-5 * diff.size and diff.max() <= 2.0 ** -11
+        rel = np.linalg.norm(rows[:n][nz].astype(np.float64) - unit[nz], axis=1)
     else:
         assert idx.docs16 is None            # no second copy of the corpus
-    nz = x.any(axis=1)
-    rel = (np.linalg.norm(x16.astype(np.float64) - x, axis=1)[nz]
-           / np.linalg.norm(x.astype(np.float64), axis=1)[nz])
+        x16 = x.astype(np.float16)
+        rel = (np.linalg.norm(x16.astype(np.float64) - x, axis=1)[nz]
+               / np.linalg.norm(x.astype(np.float64), axis=1)[nz])
     assert rel.max() <= idx.doc_rel_err
     S, I, cnt, flg = T._native.dense_topk_f16(idx.docs, idx.docs16, idx.doc_rel_err, idx.dnorm,
                                               idx.inv_norm, dev(q), 100, 256, 123)
@@ -678,17 +684,19 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
         assert list(ids[i]) == ei and list(sc[i]) == es
 
 
-def test_dense_f16_rejects_rows_outside_half_range(T):
+def test_dense_f16_rows_outside_half_range(T):
+    """A value that rounds to +inf in float16: the in-flight-rounding scan must refuse the rows;
+    the float16 COPY holds normalised rows, so it takes them (and stays exact)."""
     x, _ = rand_docs(3000, 768, 5)
-    x[17, 3] = 1e6                            # rounds to +inf in float16
-    for mode in ("f16", "f16-inline"):
-        with pytest.raises(T._native.NativeError, match="float16"):
-            T.GpuIndex().set_dense(x, shortlist=mode)
-    idx = T.GpuIndex().set_dense(x, shortlist="f32")
+    x[17, 3] = 1e6
+    with pytest.raises(T._native.NativeError, match="float16"):
+        T.GpuIndex().set_dense(x, shortlist="f16-inline")
     q = x[:4].copy()
-    S, I, cnt, _ = idx.dense_search(dev(q), 10)
     Se, Ie, cnte = CO.dense_topk_exact(x, q, 10)
-    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "wide-range rows")
+    for mode in ("f32", "f16"):
+        idx = T.GpuIndex().set_dense(x, shortlist=mode)
+        S, I, cnt, _ = idx.dense_search(dev(q), 10)
+        assert_topk_equal(S, I, cnt, Se, Ie, cnte, "wide-range rows " + mode)
 
 
 @pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
@@ -764,18 +772,26 @@ def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
 
 
 def test_dense_rows_below_half_precision_range(T):
-    """Rows scaled into float16's subnormal range: "auto" answers with the fp32 scan, the f16
-    flavours refuse; results stay exact."""
+    """Rows scaled into float16's subnormal range: the in-flight-rounding scan refuses them, the
+    normalised float16 copy does not care about the scale; results stay exact."""
     x, rng = rand_docs(20000, 768, 12)
     x *= 1e-6
     q = (x[:5] + 1e-7 * rng.standard_normal((5, 768))).astype(np.float32)
     idx = T.GpuIndex().set_dense(x)
-    assert idx.shortlist == "f32"
+    assert idx.shortlist == "f16" and idx.doc_rel_err < 6e-4
     S, I, cnt, nres = idx.dense_search(dev(q), 20)
     Se, Ie, cnte = CO.dense_topk_exact(x, q, 20)
     assert_topk_equal(S, I, cnt, Se, Ie, cnte, "tiny rows")
     with pytest.raises(T._native.NativeError, match="float16"):
-        T.GpuIndex().set_dense(x, shortlist="f16")
+        T.GpuIndex().set_dense(x, shortlist="f16-inline")
+    T.GpuIndex.AUTO_COPY_FRACTION, keep = 0.0, T.GpuIndex.AUTO_COPY_FRACTION
+    try:
+        idx = T.GpuIndex().set_dense(x)      # no room for a copy and the rows do not fit float16
+        assert idx.shortlist == "f32"
+        S, I, cnt, nres = idx.dense_search(dev(q), 20)
+        assert_topk_equal(S, I, cnt, Se, Ie, cnte, "tiny rows f32")
+    finally:
+        T.GpuIndex.AUTO_COPY_FRACTION = keep
 
 
 def test_dense_auto_shortlist_choice(T):
@@ -786,12 +802,13 @@ def test_dense_auto_shortlist_choice(T):
     try:
         idx = T.GpuIndex().set_dense(x)
         assert idx.shortlist == "f16-inline" and idx.docs16 is None
+        x[5, 7] = -2e5                       # does not fit float16 as it is
+        idx = T.GpuIndex().set_dense(x)
+        assert idx.shortlist == "f32" and idx.docs16 is None and idx.doc_rel_err == 0.0
     finally:
         T.GpuIndex.AUTO_COPY_FRACTION = keep
+    assert T.GpuIndex().set_dense(x).shortlist == "f16"                    # the copy is normalised
     assert T.GpuIndex().set_dense(x[:, :256].copy()).shortlist == "f32"   # no f16 kernel at dim 256
-    x[5, 7] = -2e5
-    idx = T.GpuIndex().set_dense(x)
-    assert idx.shortlist == "f32" and idx.docs16 is None and idx.doc_rel_err == 0.0
 
 
 def test_bench_multi_rank_control_flow():

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in thr_hip.h but not exported"
     assert sorted(T._native.EXPORTED_SYMBOLS) == names
-    assert lib.thr_abi_version() == 2
+    assert lib.thr_abi_version() == T._native.ABI_VERSION == 3
     assert lib.thr_error_string(-3) == b"workspace too small"
 
 
@@ -41,11 +41,11 @@ def test_host_side_planning_functions():
     """Sizes and the query-tile choice are pure host arithmetic (no launch)."""
     N = T._native
     N.load()
-    # f16 copy scan: 64-query tiles, or 96 when the batch's tile count fills the CUs better
-    assert N.dense_f16_query_tile(768, True, 1024) == 64      # 16 tiles of 64 = one round
-    assert N.dense_f16_query_tile(768, True, 1536) == 96      # 16 tiles of 96 vs 24 of 64
-    assert N.dense_f16_query_tile(768, True, 3072) == 96
-    assert N.dense_f16_query_tile(1024, True, 1536) == 64     # 96 x 1024 halves do not fit LDS
+    # f16 copy scan: 32 queries per wave (their B operands live in registers); 8 waves per
+    # block, 4 at dim 1024 (256 B-operand registers: one wave per SIMD)
+    assert N.dense_f16_query_tile(768, True, 1024) == 256
+    assert N.dense_f16_query_tile(512, True, 1536) == 256
+    assert N.dense_f16_query_tile(1024, True, 1536) == 128
     assert N.dense_f16_query_tile(768, False, 1536) == 64     # in-flight rounding: transpose tiles
     assert N.dense_f16_query_tile(1024, False, 1536) == 32
     assert N.dense_f16_query_tile(640, True, 64) == 0         # no f16 kernel at that dim

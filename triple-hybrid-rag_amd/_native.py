@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -57,6 +57,7 @@ _SIGNATURES = {
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
+    "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
                              _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32]),
@@ -314,6 +315,21 @@ def dense_scan_probe_f16(docs, docs16, inv_norm, queries, workspace: torch.Tenso
     _check(load().thr_dense_scan_probe_f16(pd, ph, pi, n, d, pq, queries.shape[0], pw,
                                            workspace.numel() * workspace.element_size(),
                                            _stream()), "thr_dense_scan_probe_f16")
+
+
+def dense_scan_stamps_f16(docs16, n_docs: int, queries_n: int, workspace: torch.Tensor):
+    """Phase stamps of the float16-copy scan -> int64 [n_waves, 8] (see thr_hip.h)."""
+    ph = _dev(docs16, torch.float16, "docs16", 2)
+    d = docs16.shape[1]
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    nbytes = workspace.numel() * workspace.element_size()
+    nw = C.c_int(0)
+    _check(load().thr_dense_scan_stamps_f16(ph, n_docs, d, queries_n, pw, nbytes, None, C.byref(nw),
+                                            _stream()), "thr_dense_scan_stamps_f16")
+    out = torch.zeros((nw.value, 8), dtype=torch.int64, device=docs16.device)
+    _check(load().thr_dense_scan_stamps_f16(ph, n_docs, d, queries_n, pw, nbytes, out.data_ptr(),
+                                            C.byref(nw), _stream()), "thr_dense_scan_stamps_f16")
+    return out
 
 
 # --------------------------------------------------------------------- a3

@@ -301,7 +301,7 @@ __device__ __forceinline__ ScanSlot scan_slot(int n_qtiles) {
 
 #include "dense_scan_mfma.hpp"
 #include "dense_scan_f16.hpp"
-#include "dense_scan_f16p.hpp"
+#include "dense_scan_f16q.hpp"
 namespace thr {
 
 // K3b: split a tile's mixed candidate list into the per-query lists K4 reads.  Each block
@@ -384,6 +384,42 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
         __syncthreads();
     }
     *n_greater = greater;
+    return prefix;
+}
+
+// Same select over items each thread enumerates itself: keyfn(u), u in [0, my_n) (the
+// candidate lists of select_rescore: a thread's items are my_ptr[u * my_stride]).
+template <typename KeyFn>
+__device__ uint32_t block_radix_select_local(KeyFn keyfn, int my_n, int kk, int* hist, int* bc) {
+    uint32_t prefix = 0, mask = 0;
+    int remaining = kk;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int u0 = 0; u0 < my_n; u0 += 8) {
+            uint32_t key[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) key[u] = u0 + u < my_n ? keyfn(u0 + u) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u0 + u < my_n && (key[u] & mask) == prefix) atomicAdd(&hist[(key[u] >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int cum = 0, b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= remaining) break;
+                cum += hist[b];
+            }
+            bc[0] = b;
+            bc[1] = cum;
+        }
+        __syncthreads();
+        remaining -= bc[1];
+        prefix |= (uint32_t)bc[0] << shift;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
     return prefix;
 }
 
@@ -586,7 +622,8 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
     double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores,
     int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts,
-    uint32_t* __restrict__ out_flags, const uint32_t* __restrict__ redo_flags) {
+    uint32_t* __restrict__ out_flags, const uint32_t* __restrict__ redo_flags, int nseg,
+    int seg_cap) {
     if (redo_flags && (redo_flags[blockIdx.x] & (THR_FLAG_CERTIFIED | THR_FLAG_OVERFLOW))) return;
     extern __shared__ float4 lds_sel[];  // [dim/4] query | hist (band) / 4 wave stage tiles (rescore)
     __shared__ int aux[8];
@@ -606,21 +643,50 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const double eq = qerr ? (double)qerr[q] : 0.0;
     const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
     const Cand* c = cand + (int64_t)q * CAND_CAP;
-    const int cnt = cand_cnt[q];
-    const bool overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
-    // Only slots [0, min(cnt, CAND_CAP)) were written.  (Round 1 read all CAND_CAP slots whenever
-    // the TILE list had overflowed, even for a query of that tile with few candidates of its
-    // own: stale workspace words became row indices -> out-of-bounds gathers, the rc 134 abort
-    // of gpurun_out/t1.log.  An overflowed query is never certified; thr_dense_rescue redoes it.)
-    const int n = cnt < CAND_CAP ? cnt : CAND_CAP;
+    // A thread's candidates are my_ptr[u * my_stride], u in [0, my_n).
+    //   nseg == 0  one flat list of cand_cnt[q] entries (K3b's output): thread t takes t, t+256, ..
+    //   nseg  > 0  dense_scan_f16q's layout: nseg segments of seg_cap slots, segment s filled by
+    //              ONE lane of the scan with cand_cnt[q * nseg + s] entries (a count above seg_cap
+    //              means entries were dropped); 256 / nseg threads share a segment.
+    const Cand* my_ptr;
+    int my_stride, my_n;
+    bool overflow;
+    int n;
+    if (nseg == 0) {
+        const int cnt = cand_cnt[q];
+        overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
+        // Only slots [0, min(cnt, CAND_CAP)) were written.  (Round 1 read all CAND_CAP slots
+        // whenever the TILE list had overflowed, even for a query of that tile with few
+        // candidates of its own: stale workspace words became row indices -> out-of-bounds
+        // gathers, the rc 134 abort of gpurun_out/t1.log.  An overflowed query is never
+        // certified; thr_dense_rescue redoes it.)
+        n = cnt < CAND_CAP ? cnt : CAND_CAP;
+        my_ptr = c + threadIdx.x;
+        my_stride = SEL_THREADS;
+        my_n = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
+    } else {
+        const int tps = SEL_THREADS / nseg;   // host keeps nseg <= SEL_THREADS
+        const int sg = threadIdx.x / tps, r = threadIdx.x % tps;
+        int sc = sg < nseg ? cand_cnt[(int64_t)q * nseg + sg] : 0;
+        const bool over = sc > seg_cap;
+        sc = sc < seg_cap ? sc : seg_cap;
+        my_ptr = c + (int64_t)sg * seg_cap + r;
+        my_stride = tps;
+        my_n = sc > r ? (sc - r + tps - 1) / tps : 0;
+        overflow = __syncthreads_or(over) != 0;
+        __shared__ int n_total;
+        if (threadIdx.x == 0) n_total = 0;
+        __syncthreads();
+        if (my_n) atomicAdd(&n_total, my_n);
+        __syncthreads();
+        n = n_total;
+    }
 
     // candidates this thread keeps in registers (loads in flight while the query is staged)
     Cand mine[SEL_REG];
 #pragma unroll
-    for (int u = 0; u < SEL_REG; ++u) {
-        const int i = threadIdx.x + u * SEL_THREADS;
-        mine[u] = i < n ? c[i] : Cand{-INFINITY, 0u};
-    }
+    for (int u = 0; u < SEL_REG; ++u)
+        mine[u] = u < my_n ? my_ptr[(int64_t)u * my_stride] : Cand{-INFINITY, 0u};
     for (int i = threadIdx.x; i < dim / 4; i += SEL_THREADS)
         lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
     for (int i = threadIdx.x; i < CAPB; i += SEL_THREADS) {
@@ -640,9 +706,6 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     }
     const double qn_hi = sqrt(wsum[0] + wsum[1] + wsum[2] + wsum[3]) * (1.0 + 1e-6);
 
-    auto key_of = [&](int i) -> uint32_t {  // candidate i's key: registers first, then memory
-        return fkey(c[i].score);
-    };
     float floor32 = tau[q];
     bool band_done = false;
     if (n > k) {
@@ -656,13 +719,13 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
 #pragma unroll
             for (int u = 0; u < SEL_REG; ++u) {
                 const uint32_t key = fkey(mine[u].score);
-                if (threadIdx.x + u * SEL_THREADS < n) {
+                if (u < my_n) {
                     if (pass == 0) atomicAdd(&hist[key >> 20], 1);
                     else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
                 }
             }
-            for (int i = threadIdx.x + SEL_REG * SEL_THREADS; i < n; i += SEL_THREADS) {
-                const uint32_t key = key_of(i);
+            for (int u = SEL_REG; u < my_n; ++u) {
+                const uint32_t key = fkey(my_ptr[(int64_t)u * my_stride].score);
                 if (pass == 0) atomicAdd(&hist[key >> 20], 1);
                 else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
             }
@@ -679,15 +742,17 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
             // count and collect in one sweep; past CAPB rows only the count matters
 #pragma unroll
             for (int u = 0; u < SEL_REG; ++u)
-                if (threadIdx.x + u * SEL_THREADS < n && mine[u].score >= band_lo) {
+                if (u < my_n && mine[u].score >= band_lo) {
                     const int p = atomicAdd(&n_sel, 1);
                     if (p < CAPB) s_id[p] = mine[u].doc;
                 }
-            for (int i = threadIdx.x + SEL_REG * SEL_THREADS; i < n; i += SEL_THREADS)
-                if (c[i].score >= band_lo) {
+            for (int u = SEL_REG; u < my_n; ++u) {
+                const Cand e = my_ptr[(int64_t)u * my_stride];
+                if (e.score >= band_lo) {
                     const int p = atomicAdd(&n_sel, 1);
-                    if (p < CAPB) s_id[p] = c[i].doc;
+                    if (p < CAPB) s_id[p] = e.doc;
                 }
+            }
             __syncthreads();
             if (n_sel <= CAPB) {
                 // rows outside the band: uncollected ones are below tau, collected ones below band_lo
@@ -703,26 +768,31 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     if (!band_done) {
         // the band does not fit the block (or the list is short): the kprime best, exactly
         if (n > kprime) {
-            int greater;
-            uint32_t tkey = block_radix_select([&](int i) { return fkey(c[i].score); }, n, kprime,
-                                               hist, bc, &greater);
+            const uint32_t tkey = block_radix_select_local(
+                [&](int u) { return fkey(my_ptr[(int64_t)u * my_stride].score); }, my_n, kprime, hist, bc);
             floor32 = fkey_inv(tkey);
-            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
-                if (fkey(c[i].score) > tkey) {
-                    int p = atomicAdd(&n_sel, 1);
-                    s_id[p] = c[i].doc;
+            for (int u = 0; u < my_n; ++u) {
+                const Cand e = my_ptr[(int64_t)u * my_stride];
+                if (fkey(e.score) > tkey) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    s_id[p] = e.doc;
                 }
+            }
             __syncthreads();
-            for (int i = threadIdx.x; i < n; i += SEL_THREADS)
-                if (fkey(c[i].score) == tkey) {
-                    int p = atomicAdd(&n_sel, 1);
-                    if (p < kprime) s_id[p] = c[i].doc;
+            for (int u = 0; u < my_n; ++u) {
+                const Cand e = my_ptr[(int64_t)u * my_stride];
+                if (fkey(e.score) == tkey) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    if (p < kprime) s_id[p] = e.doc;
                 }
+            }
             __syncthreads();
             if (threadIdx.x == 0 && n_sel > kprime) n_sel = kprime;
         } else {
-            for (int i = threadIdx.x; i < n; i += SEL_THREADS) s_id[i] = c[i].doc;
-            if (threadIdx.x == 0) n_sel = n;
+            for (int u = 0; u < my_n; ++u) {
+                const int p = atomicAdd(&n_sel, 1);
+                s_id[p] = my_ptr[(int64_t)u * my_stride].doc;
+            }
         }
     }
     __syncthreads();  // also: every wave is done with hist before the stage tiles reuse it
@@ -1020,11 +1090,13 @@ __global__ __launch_bounds__(256) void merge_ranked_lists(const double* __restri
 struct DensePlan {
     int qtile, ntiles, qpad, unit, kind, row_bits, ksample, nq;
     bool packed;  // KIND_F16 only: scan of the fragment-major copy (else float32 rows, rounded in flight)
+    bool qreg;    // = packed: dense_scan_f16q[s] (queries in registers, rows through LDS); the
+                  // candidate area is written in per-lane segments
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
     bool sampled;
     int tile_cap;
-    size_t off_tau, off_qerr, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, total;
+    size_t off_tau, off_qerr, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, off_qfrag, total;
 };
 
 constexpr int R_DEFAULT = 4;
@@ -1060,45 +1132,39 @@ static int mfma_version() {
 }
 
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
-// query sub-tiles of 32 per pass on the float16 copy: 2 (64 queries, 96 KiB of LDS at dim 768)
-// when the tile fits next to the transpose tiles, else 1
-// (the fragment-major copy needs no transpose tiles: 64 queries fit at dim 1024 as well)
-static size_t f16_lds_bytes(int dim, int nq, bool packed) {
+// in-flight-rounding f16 scan (dense_scan_f16): query sub-tiles of 32 per pass -- 2 (64 queries,
+// 96 KiB of LDS at dim 768) when the tile fits next to the transpose tiles, else 1
+static size_t f16_lds_bytes(int dim, int nq) {
     return sizeof(_Float16) * 32 * nq * (size_t)dim +
-           (sizeof(Cand) * WBUF + (packed ? 0 : sizeof(float4) * MF2_STAGE_F4)) * H_WAVES;
+           (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * H_WAVES;
 }
-// Query sub-tiles of 32 per pass.  Inline flavour: 2 when the tile fits next to the transpose
-// tiles, else 1.  Packed flavour: 2, or 3 (96 queries: a third fewer row bytes per MFMA, but
-// ~1.2x the time per block) when it fits LDS and the batch's tile count then keeps the CUs
-// busier -- e.g. 1536 queries are 16 tiles of 96 (all 256 CUs, one round) but 24 tiles of 64
-// (192 CUs, twice the rows each); 1024 queries are 16 tiles of 64 but 11 of 96.
-static int f16_pick_nq(int dim, bool packed, int n_queries) {
-    if (!packed) return f16_lds_bytes(dim, 2, false) <= 160 * 1024 ? 2 : 1;
-    if (f16_lds_bytes(dim, 3, true) > 160 * 1024) return 2;
-    static int forced = -1;  // THR_DENSE_F16_NQ=2|3 pins the choice
-    if (forced < 0) {
-        const char* e = getenv("THR_DENSE_F16_NQ");
-        forced = e ? atoi(e) : 0;
+static int f16_pick_nq(int dim) { return f16_lds_bytes(dim, 2) <= 160 * 1024 ? 2 : 1; }
+
+// The scan over the float16 copy (queries in registers, rows through LDS): dense_scan_f16qs
+// (staggered 8-wave block) where 8 x 32 queries' B operands fit the registers of two waves per
+// SIMD, else dense_scan_f16q (4-wave blocks); THR_DENSE_F16=q forces the latter (it has the
+// stamped diagnostic build).  Read once.
+static bool qreg_staggered(int dim) {
+    static int forced_q = -1;
+    if (forced_q < 0) {
+        const char* e = getenv("THR_DENSE_F16");
+        forced_q = (e && e[0] == 'q') ? 1 : 0;
     }
-    if (forced == 2 || forced == 3) return forced;
-    auto cost = [&](int nq) {
-        const int ntq = (n_queries + 32 * nq - 1) / (32 * nq);
-        int m = 32 / ntq;            // slices per XCD that run at once (scan_grid's choice when it divides)
-        if (m < 1) m = 1;
-        const int rounds = (8 * m * ntq + 255) / 256;
-        return (nq == 3 ? 1.2 : 1.0) * (double)rounds / (double)m;
-    };
-    return cost(3) < cost(2) ? 3 : 2;
+    return !forced_q && dim <= 768;
 }
+static int qreg_waves(int dim) { return qreg_staggered(dim) ? 8 : 4; }   // 32 queries per wave
+constexpr int QREG_MAX_SEG = 256;
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
                            int dim = 0, bool packed = false) {
     DensePlan p;
     p.kind = kind;
     p.packed = kind == KIND_F16 && packed;
-    p.nq = kind == KIND_F16 ? f16_pick_nq(dim, p.packed, n_queries) : 1;
-    p.row_bits = kind == KIND_F16 ? ROW_BITS_F16 : ROW_BITS;
-    p.qtile = kind == KIND_F16 ? 32 * p.nq : (use_mfma() ? MF_QT : query_tile());
+    p.qreg = p.packed;
+    p.nq = (kind == KIND_F16 && !p.packed) ? f16_pick_nq(dim) : 1;
+    p.row_bits = (kind == KIND_F16 && !p.qreg) ? ROW_BITS_F16 : ROW_BITS;
+    p.qtile = p.qreg ? 32 * qreg_waves(dim)
+              : kind == KIND_F16 ? 32 * p.nq : (use_mfma() ? MF_QT : query_tile());
     p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
@@ -1130,12 +1196,14 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     };
     p.off_tau = take(sizeof(float) * p.qpad);
     p.off_qerr = take(sizeof(float) * p.qpad);
-    p.tile_cap = p.qtile * (CAND_CAP / 2);
-    p.off_cnt = take(sizeof(int) * p.qpad);   // off_cnt and off_tcnt are zeroed by one memset
+    p.tile_cap = p.qreg ? 1 : p.qtile * (CAND_CAP / 2);   // (no tile lists in the qreg scan)
+    // (off_cnt and off_tcnt are zeroed by one memset; the qreg scan keeps one count per segment)
+    p.off_cnt = take(sizeof(int) * p.qpad * (p.qreg ? QREG_MAX_SEG : 1));
     p.off_tcnt = take(sizeof(int) * p.ntiles);
     p.off_cand = take(sizeof(Cand) * (size_t)p.qpad * CAND_CAP);
     p.off_tlist = take(sizeof(Cand) * (size_t)p.ntiles * p.tile_cap);
     p.off_sample = take(sizeof(float) * (size_t)p.qpad * (size_t)p.sample_docs);
+    p.off_qfrag = take(p.qreg ? sizeof(_Float16) * (size_t)p.qpad * (size_t)dim : 0);
     p.total = off;
     return p;
 }
@@ -1156,13 +1224,14 @@ static int num_cus() {
 // chosen for the fullest last round of blocks, the smallest such m first (fewer, longer row
 // slices; at 32 query tiles m = 1 and the whole launch is a single round).  THR_DENSE_MAP=grid
 // restores the plain 2-D launch (x = row slice, y = query tile) for comparison.
-static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_rows) {
+static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_rows,
+                      int blocks_per_cu = 1, int m_cap = 64) {
     static int plain = -1;
     if (plain < 0) {
         const char* e = getenv("THR_DENSE_MAP");
         plain = (e && e[0] == 'g') ? 1 : 0;
     }
-    const int cus = num_cus();
+    const int cus = num_cus() * blocks_per_cu;   // block slots
     if (plain) {
         int64_t blocks = (n_row_tiles + waves - 1) / waves;
         if (blocks > cus) blocks = cus;
@@ -1172,7 +1241,7 @@ static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_r
     }
     int64_t m_max = n_row_tiles / (8 * (int64_t)waves);  // every wave gets at least one row tile
     if (m_max < 1) m_max = 1;
-    if (m_max > 64) m_max = 64;
+    if (m_max > m_cap) m_max = m_cap;
     int best_m = 1;
     double best_eff = 0.0;
     for (int m = 1; m <= (int)m_max; ++m) {
@@ -1290,64 +1359,106 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
     return launch_status();
 }
 
-// rows16 != nullptr: stream the fragment-major float16 copy (dense_scan_f16p); else stream the
-// float32 rows and round them in flight (dense_scan_f16)
+// the in-flight-rounding f16 scan: streams the float32 rows and rounds them in registers
 template <int MODE>
-static int launch_scan_f16(int dim, int nq, const float* rows32, const _Float16* rows16,
-                           const float* inv_norm, int64_t n_docs,
-                           const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
-                           int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
-                           int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    const bool packed = rows16 != nullptr;
-    const size_t lds = f16_lds_bytes(dim, nq, packed);
+static int launch_scan_f16(int dim, int nq, const float* rows32, const float* inv_norm,
+                           int64_t n_docs, const float* queries, int n_queries, int ntiles,
+                           int64_t n_row_tiles, int64_t tile_stride, const float* tau, int* tile_cnt,
+                           Cand* tile_list, int tile_cap, float* sample, int64_t sample_ld,
+                           hipStream_t st) {
+    const size_t lds = f16_lds_bytes(dim, nq);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     bool shared_rows = false;
-    // (a wave of the packed scan takes its row tiles in pairs)
-    const dim3 grid = scan_grid(ntiles, packed ? (n_row_tiles + 1) / 2 : n_row_tiles, H_WAVES,
-                                &shared_rows);
+    const dim3 grid = scan_grid(ntiles, n_row_tiles, H_WAVES, &shared_rows);
     const bool nt = scan_nt(shared_rows);
-    const void* rows = packed ? (const void*)rows16 : (const void*)rows32;
-#define THR_H_LAUNCH(KERN, ROWS)                                                                  \
+#define THR_H_LAUNCH(KERN)                                                                        \
     {                                                                                             \
         auto kern = KERN;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, ROWS, inv_norm, n_docs, queries, \
-                           n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
+        hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, rows32, inv_norm, n_docs,        \
+                           queries, n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list, \
                            tile_cap, sample, sample_ld);                                          \
-    }
-#define THR_H_PACKED(DIM, NQV)                                                                    \
-    {                                                                                             \
-        if (nt) THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, true, NQV>), (const f32x4*)rows)         \
-        else THR_H_LAUNCH((dense_scan_f16p<DIM, MODE, false, NQV>), (const f32x4*)rows)           \
     }
 #define THR_H_INLINE(DIM, NQV)                                                                    \
     {                                                                                             \
-        if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV>), rows)                        \
-        else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV>), rows)                          \
+        if (nt) THR_H_LAUNCH((dense_scan_f16<DIM, MODE, true, NQV>))                              \
+        else THR_H_LAUNCH((dense_scan_f16<DIM, MODE, false, NQV>))                                \
     }
-    const int key = dim * 10 + nq;
-    if (packed) {
-        switch (key) {
-            case 5122: THR_H_PACKED(512, 2) break;
-            case 5123: THR_H_PACKED(512, 3) break;
-            case 7682: THR_H_PACKED(768, 2) break;
-            case 7683: THR_H_PACKED(768, 3) break;
-            case 10242: THR_H_PACKED(1024, 2) break;
-            default: return THR_ERR_UNSUPPORTED;
-        }
-    } else {
-        switch (key) {
-            case 5122: THR_H_INLINE(512, 2) break;
-            case 7682: THR_H_INLINE(768, 2) break;
-            case 10241: THR_H_INLINE(1024, 1) break;
-            default: return THR_ERR_UNSUPPORTED;
-        }
+    switch (dim * 10 + nq) {
+        case 5122: THR_H_INLINE(512, 2) break;
+        case 7682: THR_H_INLINE(768, 2) break;
+        case 10241: THR_H_INLINE(1024, 1) break;
+        default: return THR_ERR_UNSUPPORTED;
     }
 #undef THR_H_INLINE
-#undef THR_H_PACKED
 #undef THR_H_LAUNCH
+    return launch_status();
+}
+
+template <int MODE, bool PROF = false>
+static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfrag, int n_qtiles,
+                            int64_t n_row_tiles, int64_t tile_stride, const float* tau, int* seg_cnt,
+                            Cand* cand, float* sample, int64_t sample_ld, hipStream_t st,
+                            int* nseg_out = nullptr, unsigned long long* stamps = nullptr,
+                            int* n_blocks = nullptr) {
+    bool shared_rows = false;
+    const bool stag = qreg_staggered(dim);
+    // a lane's candidate segment is (row slice, row half): at most 128 slices (256 segments, the
+    // threads of select_rescore)
+    const dim3 grid = scan_grid(n_qtiles, n_row_tiles, 1, &shared_rows, (!stag && dim <= 768) ? 2 : 1, 16);
+    const int nseg = 2 * (int)(grid.x / n_qtiles);
+    if (nseg_out) *nseg_out = nseg;
+    if (n_blocks) *n_blocks = (int)grid.x;
+    if (PROF && !stamps) return THR_OK;   // size query
+#define THR_QS_LAUNCH(DIM)                                                                        \
+    {                                                                                             \
+        auto kern = dense_scan_f16qs<DIM, MODE>;                                                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                           QStag<DIM>::LDS_BYTES);                                \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(QS_NW * 64), QStag<DIM>::LDS_BYTES, st,               \
+                           (const f32x4*)rows16, (const f32x4*)qfrag, n_qtiles, n_row_tiles,      \
+                           tile_stride, tau, seg_cnt, cand, CAND_CAP / nseg, sample, sample_ld);  \
+    }
+    if (stag) {
+        if (dim == 512) THR_QS_LAUNCH(512) else THR_QS_LAUNCH(768)
+        return launch_status();
+    }
+#undef THR_QS_LAUNCH
+#define THR_Q_LAUNCH(DIM)                                                                         \
+    {                                                                                             \
+        auto kern = dense_scan_f16q<DIM, MODE, PROF>;                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                           QScan<DIM>::LDS_BYTES);                                \
+        if (e != hipSuccess) return (int)e;                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(Q_NW * 64), QScan<DIM>::LDS_BYTES, st,                \
+                           (const f32x4*)rows16, (const f32x4*)qfrag, n_qtiles, n_row_tiles,      \
+                           tile_stride, tau, seg_cnt, cand, CAND_CAP / nseg, sample, sample_ld,   \
+                           stamps);                                                               \
+    }
+    switch (dim) {
+        case 512: THR_Q_LAUNCH(512) break;
+        case 768: THR_Q_LAUNCH(768) break;
+        case 1024: THR_Q_LAUNCH(1024) break;
+        default: return THR_ERR_UNSUPPORTED;
+    }
+#undef THR_Q_LAUNCH
+    return launch_status();
+}
+
+static int launch_pack_queries(int dim, const float* queries, int n_queries, int qpad,
+                               _Float16* qfrag, float* qerr, hipStream_t st) {
+    const dim3 grid((unsigned)(qpad / 32));
+    switch (dim) {
+        case 512: hipLaunchKernelGGL(pack_queries_f16<512>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
+        case 768: hipLaunchKernelGGL(pack_queries_f16<768>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
+        case 1024: hipLaunchKernelGGL(pack_queries_f16<1024>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
+        default: return THR_ERR_UNSUPPORTED;
+    }
     return launch_status();
 }
 
@@ -1396,12 +1507,19 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     Cand* cand = (Cand*)(ws + p.off_cand);
     Cand* tlist = (Cand*)(ws + p.off_tlist);
     float* sample = (float*)(ws + p.off_sample);
+    _Float16* qfrag = (_Float16*)(ws + p.off_qfrag);
+    int nseg = 0;   // qreg scan: segments per query of the candidate area (else one flat list)
     auto scan = [&](bool all, int64_t units, int64_t stride, float* smp, int64_t ld) -> int {
+        if (p.qreg)
+            return all ? launch_scan_f16q<MODE_ALL>(dim, docs16, qfrag, p.ntiles, units, stride,
+                                                    nullptr, nullptr, nullptr, smp, ld, st)
+                       : launch_scan_f16q<MODE_FILTER>(dim, docs16, qfrag, p.ntiles, units, stride,
+                                                       tau, cnt, cand, nullptr, 0, st, &nseg);
         if (h)
-            return all ? launch_scan_f16<MODE_ALL>(dim, p.nq, docs, docs16, inv_norm, n_docs, queries,
+            return all ? launch_scan_f16<MODE_ALL>(dim, p.nq, docs, inv_norm, n_docs, queries,
                                                    n_queries, p.ntiles, units, stride, nullptr,
                                                    nullptr, nullptr, 0, smp, ld, st)
-                       : launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, docs16, inv_norm, n_docs, queries,
+                       : launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, inv_norm, n_docs, queries,
                                                       n_queries, p.ntiles, units, stride, tau, tcnt,
                                                       tlist, p.tile_cap, nullptr, 0, st);
         return all ? launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
@@ -1414,31 +1532,38 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
     if (e != hipSuccess) return (int)e;
     int rc;
+    // (the qreg scan's query image comes with the query-side error term; kth_select then skips it)
+    if (p.qreg && (rc = launch_pack_queries(dim, queries, n_queries, p.qpad, qfrag, qerr, st))) return rc;
+    float* qerr_k2 = p.qreg ? nullptr : qerr;
     if (p.sampled) {
         if ((rc = scan(true, p.sample_groups, p.sample_stride, sample, p.sample_docs))) return rc;
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
-                           (int)p.sample_docs, p.ksample, queries, n_queries, dim, tau, qerr);
+                           (int)p.sample_docs, p.ksample, queries, n_queries, dim, tau, qerr_k2);
     } else {
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
-                           (int64_t)0, 0, p.ksample, queries, n_queries, dim, tau, qerr);
+                           (int64_t)0, 0, p.ksample, queries, n_queries, dim, tau, qerr_k2);
     }
     if ((rc = launch_status())) return rc;
     if ((rc = scan(false, p.groups, 1, nullptr, 0))) return rc;
-    hipLaunchKernelGGL(bucket_candidates, dim3(BUCKET_BLOCKS, p.ntiles), dim3(256), 0, st, tcnt,
-                       tlist, p.tile_cap, p.qtile, p.row_bits, cnt, cand);
-    if ((rc = launch_status())) return rc;
+    if (!p.qreg) {  // the qreg scan writes the per-query lists itself
+        hipLaunchKernelGGL(bucket_candidates, dim3(BUCKET_BLOCKS, p.ntiles), dim3(256), 0, st, tcnt,
+                           tlist, p.tile_cap, p.qtile, p.row_bits, cnt, cand);
+        if ((rc = launch_status())) return rc;
+    }
     const double u = 5.9604644775390625e-08;
     const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
     hipLaunchKernelGGL(select_rescore<THR_DENSE_MAX_K>, dim3(n_queries), dim3(SEL_THREADS),
                        select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
                        tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
-                       out_ids, out_counts, out_flags, (const uint32_t*)nullptr);
+                       out_ids, out_counts, out_flags, (const uint32_t*)nullptr, nseg,
+                       nseg ? CAND_CAP / nseg : 0);
     if ((rc = launch_status())) return rc;
     // second chance with a 1024-row band for the queries whose band did not fit 256 rows
     hipLaunchKernelGGL(select_rescore<SEL_BIG_BAND>, dim3(n_queries), dim3(SEL_THREADS),
                        select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
                        tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
-                       out_ids, out_counts, out_flags, (const uint32_t*)out_flags);
+                       out_ids, out_counts, out_flags, (const uint32_t*)out_flags, nseg,
+                       nseg ? CAND_CAP / nseg : 0);
     return launch_status();
 }
 
@@ -1482,7 +1607,8 @@ extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_q
 
 extern "C" int thr_dense_f16_query_tile(int dim, int packed, int n_queries) {
     if (dim != 512 && dim != 768 && dim != 1024) return 0;
-    return 32 * f16_pick_nq(dim, packed != 0, n_queries > 0 ? n_queries : 1);
+    (void)n_queries;
+    return packed ? 32 * qreg_waves(dim) : 32 * f16_pick_nq(dim);
 }
 
 extern "C" size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim) {
@@ -1498,13 +1624,18 @@ extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(max_rel_err, 0, sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    if (docs16) {  // rows past n_docs in the last tile of 32 stay zero
-        e = hipMemsetAsync(docs16, 0, thr_dense_f16_copy_bytes(n_docs, dim), st);
-        if (e != hipSuccess) return (int)e;
+    if (docs16) {
+        // normalised rows, NaN for rows without an embedding and for the padding of the last tile
+        THR_RETURN_IF(dim % 16 != 0, THR_ERR_UNSUPPORTED);
+        const int64_t n_pad = (n_docs + 31) / 32 * 32;
+        hipLaunchKernelGGL(quantize_f16_norm, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, st,
+                           docs, n_docs, dim, reinterpret_cast<_Float16*>(docs16),
+                           reinterpret_cast<unsigned int*>(max_rel_err));
+        return launch_status();
     }
-    hipLaunchKernelGGL(quantize_f16, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, docs,
-                       n_docs, dim, reinterpret_cast<_Float16*>(docs16),
-                       reinterpret_cast<unsigned int*>(max_rel_err));
+    // measure only: the in-flight-rounding scan rounds the rows as they are
+    hipLaunchKernelGGL(measure_f16_error, dim3((unsigned)((n_docs + 3) / 4)), dim3(256), 0, st, docs,
+                       n_docs, dim, reinterpret_cast<unsigned int*>(max_rel_err));
     return launch_status();
 }
 
@@ -1564,12 +1695,42 @@ extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs1
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
+    if (p.qreg) {
+        // the query image and tau are the last thr_dense_topk_f16's
+        return launch_scan_f16q<MODE_FILTER>(dim, reinterpret_cast<const _Float16*>(docs16),
+                                             (const _Float16*)(ws + p.off_qfrag), p.ntiles, p.groups,
+                                             1, (const float*)(ws + p.off_tau), (int*)(ws + p.off_cnt),
+                                             (Cand*)(ws + p.off_cand), nullptr, 0, st);
+    }
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
-    return launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, reinterpret_cast<const _Float16*>(docs16), inv_norm,
+    return launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, inv_norm,
                                         n_docs, queries, n_queries, p.ntiles, p.groups, 1,
                                         (const float*)(ws + p.off_tau), (int*)(ws + p.off_tcnt),
                                         (Cand*)(ws + p.off_tlist), p.tile_cap, nullptr, 0, st);
+}
+
+extern "C" int thr_dense_scan_stamps_f16(const uint16_t* docs16, int64_t n_docs, int dim,
+                                         int n_queries, void* workspace, size_t workspace_bytes,
+                                         unsigned long long* stamps, int* h_n_waves,
+                                         thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!docs16 || !workspace || !h_n_waves, THR_ERR_INVALID);
+    THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0, THR_ERR_INVALID);
+    // (only the 4-wave-block kernel has a stamped build: THR_DENSE_F16=q, or dim 1024)
+    THR_RETURN_IF(qreg_staggered(dim), THR_ERR_UNSUPPORTED);
+    const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim, true);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = 0;
+    int rc = launch_scan_f16q<MODE_FILTER, true>(
+        dim, reinterpret_cast<const _Float16*>(docs16), (const _Float16*)(ws + p.off_qfrag), p.ntiles,
+        p.groups, 1, (const float*)(ws + p.off_tau), (int*)(ws + p.off_cnt), (Cand*)(ws + p.off_cand),
+        nullptr, 0, st, nullptr, stamps, &blocks);
+    *h_n_waves = blocks * qreg_waves(dim);
+    return rc;
 }
 
 extern "C" size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries) {

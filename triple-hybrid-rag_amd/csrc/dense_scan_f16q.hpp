@@ -1,0 +1,562 @@
+// Shortlist scan with the QUERIES in registers and the ROWS shared through LDS
+// (thr_dense_topk_f16 over the fragment-major float16 copy; the default f16 scan since round 2).
+//
+// Why (profiles/README.md, round 2): the round-1 kernel (dense_scan_f16p) kept 96 queries in
+// LDS and let every wave stream its own rows from L2 -- 8 KiB of row fragments per 24 MFMAs and
+// wave, 42.7 B/clk/CU at the full matrix rate against an L1 path of 64 B/clk.  Its waves sat in
+// s_waitcnt 44 % of the time and the matrix pipe was 52 % busy.  Here the operand roles are
+// swapped, which takes the row loads off the waves' critical path altogether:
+//
+//   * a wave owns 32 queries for the whole launch and keeps their float16 image as the B operands
+//     of all DIM/16 k-steps in registers (192 VGPRs at dim 768) -- loaded once, coalesced, from
+//     the fragment-major query image pack_queries_f16 writes;
+//   * rows reach LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no LDS store instructions) in
+//     HALF tiles (32 rows x DIM/2: 24 KiB at dim 768): the copy is fragment-major, so each 1 KiB
+//     piece IS the A operand of one k-step and lands lane-linear; one conflict-free ds_read_b128
+//     per MFMA and wave;
+//   * a block is 4 waves (one per SIMD, 128 queries) and TWO blocks share a CU (2 x 76 KiB of
+//     LDS at dim 768).  The first version of this kernel ran ONE 8-wave block per CU and its phase
+//     stamps (profiles/r2_scan_stamps_v1.json) showed why that is wrong: the older wave of a SIMD
+//     takes the matrix pipe for its whole k-loop, the younger runs after it, and the block-wide
+//     barrier then holds everybody until the last wave has emitted -- the pipe idled 40 % of
+//     every tile.  Two independent blocks have independent barriers, so one block's DMA issue,
+//     emit and barrier wait run under the other block's MFMAs;
+//   * ring of NB half-tile buffers, ONE workgroup barrier per half tile: wait for the own pieces
+//     of half-tile j (counted vmcnt: the next half-tile's pieces stay in flight), barrier
+//     (everybody's pieces of j have landed, everybody is done reading j-1), then the pieces of
+//     j+NB-1 are issued into j-1's buffer BETWEEN the MFMAs of j.
+//
+// The copy holds the rows NORMALISED (d/||d|| rounded to float16, thr_dense_quantize_f16) with
+// NaN for rows without an embedding and for the padding rows of the last tile: an accumulator
+// is then the scan score itself (no 1/||d|| gather) and `acc >= tau` is false for every row that
+// must not be emitted -- the fast path of the epilogue is one compare + branch per accumulator
+// register.  A lane that passes writes (score, row) straight to global memory at its OWN cursor:
+// lane (query c, row half h) of the block working on row slice `slice` owns segment
+// 2 * slice + h of query c's candidate area, so there is no staging, no atomic and no flush --
+// the 1400 cycles per tile the LDS-staged, atomically flushed emit of the first version took
+// (the returning atomics also drained the DMA queue).  select_rescore reads the segments in
+// place (cand_cnt[q * nseg + s] entries each).
+#pragma once
+
+namespace thr {
+
+constexpr int Q_RING = 4;  // A fragments in flight per wave
+constexpr int Q_NW = 4;    // waves per block, 32 queries each
+
+template <int DIM>
+struct QScan {
+    static constexpr int KS = DIM / 16;             // k-steps = 1 KiB pieces per row tile
+    static constexpr int HS = KS / 2;               // ... per half tile
+    static constexpr int HALF_BYTES = HS * 1024;
+    static constexpr int PER_CU = DIM <= 768 ? 2 : 1;   // blocks per CU (256 B-operand VGPRs at 1024)
+    static constexpr int NB = (160 * 1024 / PER_CU) / HALF_BYTES > 4 ? 4 : (160 * 1024 / PER_CU) / HALF_BYTES;
+    static constexpr int PER = HS / Q_NW;           // pieces a wave issues per half tile
+    static constexpr int LDS_BYTES = NB * HALF_BYTES;
+    static_assert(HS % Q_NW == 0 && NB >= 3, "half tile must split evenly over the waves; >= 3 buffers");
+};
+
+// queries float32 [n, DIM] -> fragment-major float16 image [qpad/32][KS][64 lanes][8 halves]
+// (lane (c, h) of k-step s holds dims 16 s + 8 h .. + 8 of query 32 tile + c: the B operand of
+// v_mfma_f32_32x32x16_f16), zeros for padding queries, plus
+// qerr[q] = ||fp16(q) - q|| / ||q|| rounded up (the query-side term of the f16 certificate).
+// One wave per 32 queries.
+template <int DIM>
+__global__ __launch_bounds__(64) void pack_queries_f16(const float* __restrict__ queries,
+                                                       int n_queries, f32x4* __restrict__ qfrag,
+                                                       float* __restrict__ qerr) {
+    constexpr int KS = DIM / 16;
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    const int q = blockIdx.x * 32 + c;
+    double e = 0.0, nn = 0.0;
+#pragma unroll 4
+    for (int s = 0; s < KS; ++s) {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+        if (q < n_queries) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(queries + (int64_t)q * DIM + 16 * s + 8 * h);
+            lo = src[0];
+            hi = src[1];
+        }
+        const f32x4 packed = pack_f16x8(lo, hi);
+        qfrag[((int64_t)blockIdx.x * KS + s) * 64 + lane] = packed;
+        const half8 hv = __builtin_bit_cast(half8, packed);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? lo[j] : hi[j - 4];
+            const double d = (double)v - (double)(float)hv[j];
+            e += d * d;
+            nn += (double)v * (double)v;
+        }
+    }
+    e += __shfl_xor(e, 32, WAVE);
+    nn += __shfl_xor(nn, 32, WAVE);
+    if (h == 0) {
+        float rel = nn > 0.0 ? (float)sqrt(e / nn) : 0.f;
+        qerr[q] = __uint_as_float(__float_as_uint(rel) + 1u);
+    }
+}
+
+// The k-loop of one half tile, fully unrolled: wait for the A fragment of step S (the Q_RING - 1
+// younger reads stay in flight), multiply, refill the ring slot with step S + Q_RING, and after
+// every fourth MFMA issue one DMA piece of the half tile NB-1 ahead.  The LDS reads are inline
+// asm (hipcc would wait vmcnt(0) before an LDS read that may alias an LDS-DMA in flight); the
+// "+v" on the waited fragment orders the MFMA behind the wait.  (Plain functions, not lambdas:
+// asm operands do not capture.)
+#define QS_RD(dst, ks) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"((ks) * 1024) : "memory")
+template <int S, int HS>
+__device__ __forceinline__ void qs_fill(f32x4 (&a)[Q_RING], uint32_t abase) {
+    if constexpr (S < Q_RING && S < HS) {
+        QS_RD(a[S], S);
+        qs_fill<S + 1, HS>(a, abase);
+    }
+}
+// K0 = first k-step of this half (0 or HS) in the B operand array
+template <int S, int HS, int K0, int KS, int PER, typename Issue>
+__device__ __forceinline__ void qs_steps(f32x4 (&a)[Q_RING], const f32x4 (&bq)[KS], f32x16& acc,
+                                         uint32_t abase, Issue& issue_piece) {
+    if constexpr (S < HS) {
+        constexpr int left = HS - S - 1 < Q_RING - 1 ? HS - S - 1 : Q_RING - 1;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % Q_RING]) : "n"(left) : "memory");
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[S % Q_RING]),
+                                                     __builtin_bit_cast(half8, bq[K0 + S]), acc, 0, 0, 0);
+        if constexpr (S + Q_RING < HS) QS_RD(a[S % Q_RING], S + Q_RING);
+        constexpr int every = HS / PER;
+        if constexpr (S % every == 1 && S / every < PER) issue_piece(std::integral_constant<int, S / every>{});
+        qs_steps<S + 1, HS, K0, KS, PER>(a, bq, acc, abase, issue_piece);
+    }
+}
+#undef QS_RD
+
+// PROF: diagnostic build (thr_dense_scan_stamps_f16): s_memtime stamps around the phases of the
+// half-tile loop, summed per wave into stamps[(block * 4 + wave) * 8 + {0: wait for the own DMA
+// pieces, 1: barrier, 2: ring fill, 3: k-loop (with the DMA issue), 4: emit, 5: half tiles,
+// 6: whole loop, 7: HW_ID}].  Each stamp drains the wave's LDS/SMEM queue, so the build is slower
+// than the real one; it only says where the time goes.
+template <int DIM, int MODE, bool PROF = false>
+__global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q(
+    const f32x4* __restrict__ packed, const f32x4* __restrict__ qfrag, int n_qtiles,
+    int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
+    int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
+    float* __restrict__ sample_scores, int64_t sample_ld,
+    unsigned long long* __restrict__ stamps = nullptr) {
+    using C = QScan<DIM>;
+    constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER;
+    extern __shared__ f32x4 lds_rows[];  // NB half-tile buffers
+
+    const ScanSlot slot = scan_slot(n_qtiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q32 = slot.qtile * Q_NW + wave;  // this wave's tile of 32 queries
+
+    // B operands: the wave's 32 queries, all k-steps, in registers for the whole launch
+    f32x4 bq[KS];
+    static_for<0, KS>([&](auto s) {
+        bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+    });
+    const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
+    // Retire these loads HERE, visibly to hipcc: left pending, their first use (the first MFMA
+    // of the tile loop) gets an s_waitcnt vmcnt(0) on every trip, which would drain the DMA
+    // of the next half tiles each time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    // the lane's private candidate segment (MODE_FILTER): query q32*32+c, segment 2*slice + h
+    const int nseg = 2 * slot.nslices;
+    const int64_t my_seg = (int64_t)(q32 * 32 + c) * nseg + 2 * slot.slice + h;
+    Cand* const seg = cand + (int64_t)(q32 * 32 + c) * CAND_CAP + (int64_t)(2 * slot.slice + h) * seg_cap;
+    int cur = 0;
+
+    // this block's row tiles: slice, slice + nslices, ...; half tile j = (tile j/2, dims half j&1)
+    const int64_t first = slot.slice, step = slot.nslices;
+    const int64_t n_mine = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
+    const int64_t n_half = 2 * n_mine;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_rows;
+    // piece p (wave + 4 p) of the block's j-th half tile -> buffer buf; past the end the last
+    // half tile is requested again (never read): the count of pieces in flight stays what the
+    // vmcnt waits assume
+    auto piece_src = [&](int64_t j) -> const f32x4* {
+        const int64_t jc = j < n_half ? j : n_half - 1;
+        const int64_t t = first + (jc >> 1) * step;
+        return packed + ((t * tile_stride * KS + (jc & 1) * HS + wave) * 64 + lane);
+    };
+    auto dma = [&](const f32x4* src, int buf, int p) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + p * Q_NW * 64),
+            (__attribute__((address_space(3))) void*)(size_t)(lds_base + buf * C::HALF_BYTES +
+                                                              (wave + p * Q_NW) * 1024),
+            16, 0, 0);
+    };
+    if (n_half > 0) {
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) {
+            const f32x4* src = piece_src(b);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, b, p);
+        }
+    }
+
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_loop = 0, t_prev = 0;
+    auto stamp = [&](int j) {
+        if constexpr (PROF) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (j >= 0) ph[j] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr (PROF) t_loop = __builtin_amdgcn_s_memtime();
+
+    f32x16 acc;
+    int buf = 0;
+    // one trip = one row tile = two half tiles (the accumulators run through both)
+#pragma unroll 1
+    for (int64_t i = 0; i < n_mine; ++i) {
+        // (a macro, not a lambda: asm operands do not capture)
+#define QS_HALF(hf)                                                                                \
+    {                                                                                              \
+        stamp(-1);                                                                                 \
+        /* own pieces of half tile 2i+hf done (the NB-2 younger half tiles' pieces -- and the      \
+           emit's few stores among them, which are over-waited for -- may stay in flight) */       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
+        stamp(0);                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                              \
+        stamp(1);                                                                                  \
+        const int nbuf = buf == 0 ? NB - 1 : buf - 1; /* half tile j-1's buffer */                 \
+        const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
+        auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
+        const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
+        f32x4 a[Q_RING];                                                                           \
+        qs_fill<0, HS>(a, abase);                                                                  \
+        stamp(2);                                                                                  \
+        qs_steps<0, HS, (hf) * HS, KS, PER>(a, bq, acc, abase, issue_piece);                       \
+        if constexpr (PROF) asm volatile("" : "+v"(acc));                                          \
+        stamp(3);                                                                                  \
+        buf = buf + 1 == NB ? 0 : buf + 1;                                                         \
+    }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+        QS_HALF(0)
+        QS_HALF(1)
+#undef QS_HALF
+
+        const int64_t t = first + i * step;
+        if constexpr (MODE == MODE_ALL) {
+            // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
+            float* dst = sample_scores + (int64_t)(q32 * 32 + c) * sample_ld + t * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = acc[4 * g + j];
+                    v[j] = sv == sv ? sv : -INFINITY;  // NaN: no such row / no embedding
+                }
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+            }
+        } else {
+            const uint32_t row0 = (uint32_t)(t * tile_stride * 32) + 4 * h;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                if (acc[x] >= my_tau) {  // false for NaN
+                    if (cur < seg_cap) {
+                        // (inline asm: a store hipcc can see would make it wait vmcnt(0) -- DMA
+                        // included -- at the loop's back edge)
+                        const uint64_t word = (uint64_t)__float_as_uint(acc[x]) |
+                                              ((uint64_t)(row0 + (uint32_t)((x & 3) + 8 * (x >> 2))) << 32);
+                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(seg + cur), "v"(word) : "memory");
+                    }
+                    ++cur;
+                }
+            }
+        }
+        stamp(4);
+    }
+    // nothing may still be landing in LDS when the block retires
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE == MODE_FILTER) seg_cnt[my_seg] = cur;
+    if constexpr (PROF) {
+        if (lane == 0) {
+            unsigned long long* o = stamps + ((int64_t)blockIdx.x * Q_NW + wave) * 8;
+            for (int j = 0; j < 5; ++j) o[j] = ph[j];
+            o[5] = (unsigned long long)n_half;
+            o[6] = __builtin_amdgcn_s_memtime() - t_loop;
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense_scan_f16qs: the same scan with ONE 8-wave block per CU (256 queries) whose two wave groups
+// run STAGGERED by half a tile -- the default at dim <= 768.
+//
+// What the counters of the two-blocks-per-CU kernel above said (profiles/r2_scan_v2_*.json): pipe
+// 64 % busy; the older block of a CU wins the matrix pipe and retires when 3/4 of the launch is
+// over, so the pipe is half empty for the last quarter; every CU pulls each tile twice; and the
+// chip drops its clock to 1.5-1.7 GHz under the load.  Here the 8 waves share each half tile
+// (half the DMA pieces and L2 bytes per flop) and are kept in step by one barrier per half tile,
+// but group B (waves 4-7, the younger wave of each SIMD) works one half tile behind group A:
+//
+//     interval k       A (waves 0-3)                        B (waves 4-7)
+//     k = 2i           MFMA half 2i   (k-steps 0..HS)       MFMA half 2i-1 (second half of tile i-1)
+//     k = 2i+1         MFMA half 2i+1, then EMIT tile i     EMIT tile i-1, then MFMA half 2i
+//
+// so an emit always runs under the other group's MFMAs (A is the older wave of the SIMD and gets
+// the pipe first: its MFMAs cover B's emit at the start of the interval, B's cover A's at the
+// end), and B -- whose half tile was published one barrier earlier -- has its first fragments in
+// registers before the barrier opens, which covers A's LDS latency after it.
+// Barrier k: every wave has waited for its own pieces of half tile k (3 younger half tiles'
+// pieces stay in flight); afterwards A is done with half k-1 and B with half k-2, so half k-2's
+// buffer takes the pieces of half k+4: ring of 6 half-tile buffers (144 KiB at dim 768).
+// ---------------------------------------------------------------------------------------------
+constexpr int QS_NW = 8;
+constexpr int QS_NBUF = 6;
+
+template <int DIM>
+struct QStag {
+    static constexpr int KS = DIM / 16, HS = KS / 2, HALF_BYTES = HS * 1024;
+    static constexpr int PER = HS / QS_NW;               // pieces a wave issues per half tile
+    static constexpr int LDS_BYTES = QS_NBUF * HALF_BYTES;
+    static_assert(HS % QS_NW == 0 && LDS_BYTES <= 160 * 1024, "dim 512 / 768 only");
+};
+
+template <int DIM, int MODE>
+__global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
+    const f32x4* __restrict__ packed, const f32x4* __restrict__ qfrag, int n_qtiles,
+    int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
+    int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
+    float* __restrict__ sample_scores, int64_t sample_ld) {
+    using C = QStag<DIM>;
+    constexpr int KS = C::KS, HS = C::HS, PER = C::PER, NBUF = QS_NBUF;
+    extern __shared__ f32x4 lds_rows[];  // 6 half-tile buffers
+
+    const ScanSlot slot = scan_slot(n_qtiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int q32 = slot.qtile * QS_NW + wave;
+
+    f32x4 bq[KS];
+    static_for<0, KS>([&](auto s) {
+        bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+    });
+    const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // retire these loads visibly to hipcc (see above)
+
+    const int nseg = 2 * slot.nslices;
+    const int64_t my_seg = (int64_t)(q32 * 32 + c) * nseg + 2 * slot.slice + h;
+    Cand* const seg = cand + (int64_t)(q32 * 32 + c) * CAND_CAP + (int64_t)(2 * slot.slice + h) * seg_cap;
+    int cur = 0;
+
+    const int64_t first = slot.slice, step = slot.nslices;
+    const int64_t n_mine = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
+    const int64_t n_half = 2 * n_mine;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_rows;
+    auto piece_src = [&](int64_t j) -> const f32x4* {
+        const int64_t jc = j < n_half ? j : n_half - 1;  // past the end: the last half again (never read)
+        const int64_t t = first + (jc >> 1) * step;
+        return packed + ((t * tile_stride * KS + (jc & 1) * HS + wave) * 64 + lane);
+    };
+    auto dma = [&](const f32x4* src, int buf, int p) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + p * QS_NW * 64),
+            (__attribute__((address_space(3))) void*)(size_t)(lds_base + buf * C::HALF_BYTES +
+                                                              (wave + p * QS_NW) * 1024),
+            16, 0, 0);
+    };
+    auto emit = [&](const f32x16& acc, int64_t i) {
+        const int64_t t = first + i * step;
+        if constexpr (MODE == MODE_ALL) {
+            float* dst = sample_scores + (int64_t)(q32 * 32 + c) * sample_ld + t * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float sv = acc[4 * g + j];
+                    v[j] = sv == sv ? sv : -INFINITY;
+                }
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+            }
+        }
+    };
+    // (MODE_FILTER's emit holds an asm statement and therefore is a macro, not part of the lambda)
+#define QS_EMIT(i_)                                                                                \
+    if constexpr (MODE == MODE_ALL) {                                                              \
+        emit(acc, (i_));                                                                           \
+    } else {                                                                                       \
+        const uint32_t row0 = (uint32_t)((first + (i_) * step) * tile_stride * 32) + 4 * h;        \
+        _Pragma("unroll") for (int x = 0; x < 16; ++x) {                                           \
+            if (acc[x] >= my_tau) { /* false for NaN */                                            \
+                if (cur < seg_cap) {                                                               \
+                    const uint64_t word = (uint64_t)__float_as_uint(acc[x]) |                      \
+                                          ((uint64_t)(row0 + (uint32_t)((x & 3) + 8 * (x >> 2))) << 32); \
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(seg + cur), "v"(word) : "memory"); \
+                }                                                                                  \
+                ++cur;                                                                             \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    // barrier k: own pieces of half k have landed (3 younger halves' pieces may stay in flight)
+#define QS_SYNC()                                                      \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");     \
+    __builtin_amdgcn_s_barrier();
+
+    if (n_half > 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4* src = piece_src(b);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, b, p);
+        }
+    }
+    f32x16 acc;
+    f32x4 a[Q_RING];
+    if (wave < 4) {
+        // ---- group A: half k in interval k ----
+        int buf = 0;
+#pragma unroll 1
+        for (int64_t i = 0; i < n_mine; ++i) {
+            {
+                QS_SYNC()  // barrier 2i
+                const int nbuf = buf + 4 >= NBUF ? buf + 4 - NBUF : buf + 4;
+                const f32x4* src = piece_src(2 * i + 4);
+                auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };
+                const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;
+                qs_fill<0, HS>(a, abase);
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                qs_steps<0, HS, 0, KS, PER>(a, bq, acc, abase, issue_piece);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            {
+                QS_SYNC()  // barrier 2i+1
+                const int nbuf = buf + 4 >= NBUF ? buf + 4 - NBUF : buf + 4;
+                const f32x4* src = piece_src(2 * i + 5);
+                auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };
+                const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;
+                qs_fill<0, HS>(a, abase);
+                qs_steps<0, HS, HS, KS, PER>(a, bq, acc, abase, issue_piece);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            QS_EMIT(i)
+        }
+        QS_SYNC()  // barrier 2n: B's last interval
+    } else {
+        // ---- group B: half k-1 in interval k ----
+        QS_SYNC()  // barrier 0: nothing to multiply yet
+        if (n_half > 0) {
+            const f32x4* src = piece_src(4);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, 4, p);
+        }
+        int buf = 0;  // buffer of half 2i
+#pragma unroll 1
+        for (int64_t i = 0; i < n_mine; ++i) {
+            const int buf1 = buf + 1 == NBUF ? 0 : buf + 1;       // half 2i+1
+            const int buf2 = buf1 + 1 == NBUF ? 0 : buf1 + 1;     // half 2i+2
+            {
+                QS_SYNC()  // barrier 2i+1
+                if (i > 0) {
+                    QS_EMIT(i - 1)
+                }
+                const int nbuf = buf + 5 >= NBUF ? buf + 5 - NBUF : buf + 5;   // half 2i+5
+                const f32x4* src = piece_src(2 * i + 5);
+                auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };
+                const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;
+                if (i == 0) qs_fill<0, HS>(a, abase);   // later trips: filled before the barrier
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+                qs_steps<0, HS, 0, KS, PER>(a, bq, acc, abase, issue_piece);
+                qs_fill<0, HS>(a, lds_base + buf1 * C::HALF_BYTES + lane * 16);   // half 2i+1: published at this barrier
+            }
+            {
+                QS_SYNC()  // barrier 2i+2
+                const f32x4* src = piece_src(2 * i + 6);   // into half 2i's buffer, which this group just left
+                auto issue_piece = [&](auto P) { dma(src, buf, decltype(P)::value); };
+                const uint32_t abase = lds_base + buf1 * C::HALF_BYTES + lane * 16;
+                qs_steps<0, HS, HS, KS, PER>(a, bq, acc, abase, issue_piece);
+                if (i + 1 < n_mine)
+                    qs_fill<0, HS>(a, lds_base + buf2 * C::HALF_BYTES + lane * 16);   // half 2i+2: published at this barrier
+            }
+            buf = buf2;
+        }
+        if (n_mine > 0) {
+            QS_EMIT(n_mine - 1)
+        }
+    }
+#undef QS_SYNC
+#undef QS_EMIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS
+    if constexpr (MODE == MODE_FILTER) seg_cnt[my_seg] = cur;
+}
+
+// float32 corpus -> fragment-major float16 copy of the NORMALISED rows (d * (1/||d||), round to
+// nearest even); rows with ||d|| = 0 and the padding rows of the last tile are NaN.  Also
+// max over rows of ||d16 - d/||d|| || (float64, against the exactly normalised row), rounded up,
+// via atomicMax on the float bits.  packed == nullptr: measure only.  One wave per row (rows of
+// the padded tail included).
+__global__ __launch_bounds__(256) void quantize_f16_norm(const float* __restrict__ docs,
+                                                         int64_t n_docs, int dim,
+                                                         _Float16* __restrict__ packed,
+                                                         unsigned int* __restrict__ max_err_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+    const int64_t n_pad = (n_docs + 31) / 32 * 32;
+    if (row >= n_pad) return;
+    const int64_t tile = row >> 5;
+    const int r = (int)(row & 31), ks = dim / 16;
+    const float* x = docs + row * dim;
+    double nn = 0.0;
+    if (row < n_docs)
+        for (int i = lane; i < dim; i += WAVE) nn += (double)x[i] * (double)x[i];
+    for (int m = 32; m >= 1; m >>= 1) nn += __shfl_xor(nn, m, WAVE);
+    const double dn = sqrt(nn);
+    const bool live = dn > 0.0;  // same rows thr_doc_norms gives inv_norm = 0 ("no embedding")
+    double err = 0.0;
+    for (int i = lane; i < dim; i += WAVE) {
+        const float v = live ? x[i] : 0.f;
+        const _Float16 hv = live ? (_Float16)(float)((double)v / dn) : (_Float16)__builtin_nanf("");
+        if (packed) {
+            const int s = i >> 4, hh = (i >> 3) & 1, e = i & 7;
+            packed[(((tile * ks + s) * 64) + r + 32 * hh) * 8 + e] = hv;
+        }
+        if (live) {
+            const double d = (double)v / dn - (double)(float)hv;
+            err += d * d;
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) err += __shfl_xor(err, m, WAVE);
+    if (lane == 0 && live) {
+        float rel = (float)sqrt(err);
+        rel = __uint_as_float(__float_as_uint(rel) + 1u);
+        atomicMax(max_err_bits, __float_as_uint(rel));
+    }
+}
+
+// The in-flight-rounding scan (dense_scan_f16) rounds the float32 rows AS THEY ARE: its row error
+// term is max_d ||fp16(d) - d|| / ||d|| (+inf when a value leaves the float16 range), rounded up,
+// accumulated as ordered float bits with atomicMax.  One wave per row.
+__global__ __launch_bounds__(256) void measure_f16_error(const float* __restrict__ docs, int64_t n_docs,
+                                                         int dim, unsigned int* __restrict__ max_rel_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+    if (row >= n_docs) return;
+    const float* x = docs + row * dim;
+    double err = 0.0, nrm = 0.0;
+    for (int i = lane; i < dim; i += WAVE) {
+        const float v = x[i];
+        const double d = (double)v - (double)(float)(_Float16)v;
+        err += d * d;
+        nrm += (double)v * (double)v;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        err += __shfl_xor(err, m, WAVE);
+        nrm += __shfl_xor(nrm, m, WAVE);
+    }
+    if (lane == 0 && nrm > 0.0) {
+        float rel = (float)sqrt(err / nrm);
+        rel = __uint_as_float(__float_as_uint(rel) + 1u);
+        atomicMax(max_rel_bits, __float_as_uint(rel));  // positive floats order like their bits
+    }
+}
+
+}  // namespace thr
