@@ -186,9 +186,16 @@ int thr_bm25_topk(const int64_t *rowptr /* [V+1] */, const int32_t *post_doc,
  * triple-hybrid-rag/src/triple_hybrid_rag/graph/puppygraph.py:152-167).
  * men_chunk holds GLOBAL chunk ids; only [chunk_base, chunk_base+n_chunks)
  * are scored (document sharding).  ``workspace`` >= thr_graph_workspace_bytes. */
-size_t thr_graph_workspace_bytes(int n_queries);
+size_t thr_graph_workspace_bytes(int n_queries, int64_t n_entities /* 0: no fallback tier */);
+/* Three tiers, no host round trip: small on-chip capacities, full on-chip capacities for the
+ * queries that overflowed them, and -- when the TRANSPOSED mention CSR is given (chunk ->
+ * (entity, conf) in (entity asc, mention) order; tmen_rowptr indexed by LOCAL chunk) -- a
+ * capacity-free walk in global memory for the rest, so THR_FLAG_OVERFLOW never comes back.
+ * Without it (tmen_* NULL) such a query keeps THR_FLAG_OVERFLOW and its list is incomplete. */
 int thr_graph_topk(const int64_t *ent_rowptr, const int32_t *ent_col, int64_t n_entities,
                    const int64_t *men_rowptr, const int32_t *men_chunk, const float *men_conf,
+                   const int64_t *tmen_rowptr /* [n_chunks+1] or NULL */,
+                   const int32_t *tmen_ent, const float *tmen_conf,
                    int64_t chunk_base, int64_t n_chunks, const int32_t *query_seeds,
                    int n_queries, int max_seeds, int hops, int k, double *out_scores,
                    int64_t *out_ids, int32_t *out_counts, uint32_t *out_flags, void *workspace,
@@ -215,6 +222,15 @@ int thr_maxsim(const uint16_t *qtok /* f16 [nq,q_tokens,tok_dim] */, int n_queri
                const uint16_t *dtok /* f16 [n_docs,d_tokens,tok_dim], or its packed image */,
                int64_t n_docs, int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
                float *out_scores /* [nq,n_cand] */, int dtok_packed, thr_stream_t stream);
+/* Ordering after the rerank (retrieval.py:449-455): candidate p of query q gets the maximum of
+ * scores[l][q][p] over the n_lists lists (document-sharded index: the shard that owns the
+ * candidate wrote its MaxSim score, the others -inf; list_stride in floats, 0 = n_queries * n),
+ * ``rerank_score or 0`` for a candidate nobody scored, and the first counts[q] candidates
+ * (NULL = n) are stably sorted by it, descending -> top_k ids / float64 scores / counts. */
+int thr_rerank_order(const float *scores /* [n_lists][nq,n] */, int n_lists, int64_t list_stride,
+                     const int64_t *ids /* [nq,n] */, const int32_t *counts /* [nq] or NULL */,
+                     int n_queries, int n, int top_k, int64_t *out_ids /* [nq,top_k] */,
+                     double *out_scores /* [nq,top_k] */, int32_t *out_counts, thr_stream_t stream);
 /* Index build: re-lay the token store fragment-major ([doc][32-token tile][k-step][lane][8
  * halves], the register image of the MFMA operand) so thr_maxsim(dtok_packed = 1) reads 1 KiB
  * contiguous per load instruction.  Out of place; same size as dtok. */

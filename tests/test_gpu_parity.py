@@ -276,7 +276,9 @@ def test_graph_matches_oracle(T):
 
 def test_graph_capacity_tiers(T):
     """Queries beyond the first launch's small on-chip capacities (1024 entities / 2048
-    contributions) are redone with the full ones; beyond those the overflow is reported."""
+    contributions) are redone with the full ones; beyond those (> 4096 entities) the walk runs
+    in global memory from the transposed mention CSR -- every tier gives the oracle's bits, and
+    no overflow flag comes back.  Without the transposed CSR the overflow is reported."""
     rng = np.random.default_rng(9)
     n_ent, n_chunks = 20000, 50000
     deg = np.full(n_ent, 2, dtype=np.int64)
@@ -287,25 +289,70 @@ def test_graph_capacity_tiers(T):
     ent_col[ent_rowptr[2]:ent_rowptr[3]] = rng.choice(np.arange(3, n_ent), 6000, replace=False)
     men = np.full(n_ent, 1, dtype=np.int64)
     men[1] = 3000                                      # > 2048 contributions from one entity
+    men[3] = 9000                                      # > 8192 contributions: beyond the full capacities
     men_rowptr = np.concatenate([[0], np.cumsum(men)]).astype(np.int64)
     men_chunk = rng.integers(0, n_chunks, men_rowptr[-1]).astype(np.int32)
     men_conf = rng.uniform(0.5, 1.0, men_rowptr[-1]).astype(np.float32)
-    seeds = np.array([[0, -1, -1], [1, -1, -1], [2, -1, -1], [7, 8, 9]], dtype=np.int32)
-    idx = T.GpuIndex()
-    idx.n_docs = n_chunks
-    idx.set_graph(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf)
-    for hops in (1, 2):
-        S, I, cnt, flg = T._native.graph_topk(idx.graph["ent_rowptr"], idx.graph["ent_col"],
-                                              idx.graph["men_rowptr"], idx.graph["men_chunk"],
-                                              idx.graph["men_conf"], dev(seeds), hops, 50, 0,
-                                              n_chunks)
-        flg = flg.cpu().numpy()
-        Se, Ie = O.graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, seeds, hops,
-                              n_chunks, 50)
-        ok = [q for q in range(4) if not (hops >= 1 and q == 2)]   # query 2: > 4096 entities
-        assert flg[2] & 2 and all(flg[q] & 1 for q in ok)
-        assert_topk_equal(S[ok], I[ok], cnt[ok], [Se[q] for q in ok], [Ie[q] for q in ok],
-                          [len(Se[q]) for q in ok], f"graph tiers hops={hops}")
+    seeds = np.array([[0, -1, -1], [1, -1, -1], [2, -1, -1], [7, 8, 9], [3, 2, 5]], dtype=np.int32)
+    for lo, hi in ((0, n_chunks), (20000, 45000)):     # whole corpus / a document shard
+        idx = T.GpuIndex(doc_base=lo)
+        idx.n_docs = hi - lo
+        idx.set_graph(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf)
+        G = idx.graph
+        for hops in (0, 1, 2):
+            Se, Ie = O.graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, seeds, hops,
+                                  hi - lo, 50, chunk_base=lo)
+            S, I, cnt, flg = T._native.graph_topk(G["ent_rowptr"], G["ent_col"], G["men_rowptr"],
+                                                  G["men_chunk"], G["men_conf"], dev(seeds), hops, 50,
+                                                  lo, hi - lo)
+            flg = flg.cpu().numpy()
+            big = [4] + ([2] if hops >= 1 else [])     # beyond the full on-chip capacities
+            ok = [q for q in range(5) if q not in big]
+            assert all(flg[q] & 2 for q in big) and all(flg[q] & 1 for q in ok)
+            assert_topk_equal(S[ok], I[ok], cnt[ok], [Se[q] for q in ok], [Ie[q] for q in ok],
+                              [len(Se[q]) for q in ok], f"graph tiers hops={hops}")
+            S, I, cnt = idx.graph_search(dev(seeds), 50, hops)      # with the third tier
+            assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"graph fallback hops={hops}")
+
+
+def test_rerank_order_matches_reference_sort(T, golden):
+    """thr_rerank_order = the reference's stable descending sort on ``rerank_score or 0``
+    (retrieval.py:449-455; ordering pinned by tests/golden/legacy_rerank.json), with the per-shard
+    score lists of a document-sharded index merged by max."""
+    rng = np.random.default_rng(3)
+    nq, n = 37, 100
+    ids = rng.permutation(10 ** 6)[: nq * n].reshape(nq, n).astype(np.int64)
+    sc = rng.standard_normal((nq, n)).astype(np.float32).round(1)      # many ties
+    cnt = rng.integers(0, n + 1, nq).astype(np.int32)
+    cnt[0], cnt[1] = n, 0
+    none = rng.random((nq, n)) < 0.1                                    # nobody scored: -> 0.0
+    owner = rng.integers(0, 3, (nq, n))
+    lists = np.full((3, nq, n), -np.inf, dtype=np.float32)
+    for l in range(3):
+        lists[l][(owner == l) & ~none] = sc[(owner == l) & ~none]
+    for top_k in (10, 100):
+        oi, os_, oc = T._native.rerank_order(dev(lists), dev(ids), dev(cnt), top_k)
+        oi, os_, oc = oi.cpu().numpy(), os_.cpu().numpy(), oc.cpu().numpy()
+        for q in range(nq):
+            c = int(cnt[q])
+            vals = [None if none[q, p] else float(sc[q, p]) for p in range(c)]
+            order = O.rerank_order(vals)[:top_k]
+            assert oc[q] == len(order)
+            assert list(oi[q, :len(order)]) == [int(ids[q, p]) for p in order]
+            assert list(os_[q, :len(order)]) == [vals[p] or 0.0 for p in order]
+            assert np.all(oi[q, len(order):] == -1)
+    # the reference's own ordering cases (Qwen3VLReranker.rerank with injected scores)
+    for c in golden("legacy_rerank.json")["qwen_rerank"]:
+        n_sent = len(c["documents_sent"] or [])
+        if not c["enabled"] or n_sent == 0:
+            continue
+        k = min(c["top_k"] or c["default_top_k"], n_sent)
+        s1 = np.array([c["scores"][:n_sent]], dtype=np.float32)
+        i1 = np.arange(n_sent, dtype=np.int64)[None]
+        oi, _, _ = T._native.rerank_order(dev(s1), dev(i1), None, k)
+        # float32 holds the fixture's 3-decimal scores distinctly enough: same ties, same order
+        exp = [int(o["chunk_id"][1:]) for o in c["out"]][:k]
+        assert list(oi[0].cpu().numpy()) == exp
 
 
 def test_rrf_fuse_matches_reference_python(T, golden):
@@ -644,15 +691,21 @@ def _sharded_worker(rank, world, port, n, d, out_dir):
     idx = (T.GpuIndex(doc_base=lo).set_dense(synth.dense_rows(lo, hi - lo, d))
            .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, float(sdl.item()) / n)
            .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf))
+    idx.set_tokens(synth.doc_tokens(lo, hi - lo, 32, 64))
     q = synth.dense_queries(24, d, n)
     dfq = df.numpy().copy()
     qt = synth.lexical_queries(24, dfq, 4)
     seeds = synth.graph_queries(24, n, 3)
-    res = ShardedIndex(idx).retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    sh = ShardedIndex(idx)
+    res = sh.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    rr = sh.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10, qtok=dev(synth.query_tokens(24, 32, 64)),
+                           rerank_top_k=100)
     if rank == 0:
         np.save(os.path.join(out_dir, "ids.npy"), res.ids.cpu().numpy())
         np.save(os.path.join(out_dir, "sc.npy"), res.scores.cpu().numpy())
         np.save(os.path.join(out_dir, "df.npy"), df.numpy())
+        np.save(os.path.join(out_dir, "rr_ids.npy"), rr.ids.cpu().numpy())
+        np.save(os.path.join(out_dir, "rr_sc.npy"), rr.scores.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -679,9 +732,53 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
     _, Id, _ = CO.dense_topk_exact(x, q, 100)
     _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
     _, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf, seeds, 2, n, 50)
+    rr_ids, rr_sc = np.load(tmp_path / "rr_ids.npy"), np.load(tmp_path / "rr_sc.npy")
+    dtok, qtok = synth.doc_tokens(0, n, 32, 64), synth.query_tokens(24, 32, 64)
     for i in range(24):
         ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 10)
         assert list(ids[i]) == ei and list(sc[i]) == es
+        # configs[4]: fused top-100 -> MaxSim on the owning shard -> second all-gather -> stable sort
+        fi, _ = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 100)
+        ms = CO.maxsim(qtok[i:i + 1], dtok, np.array([fi], dtype=np.int64))[0]
+        order = O.rerank_order([float(np.float32(v)) for v in ms])[:10]
+        got = list(rr_ids[i])
+        assert np.max(np.abs(rr_sc[i] - ms[[fi.index(g) for g in got]])) < 1e-4
+        # identical order wherever the oracle's MaxSim scores are more than 2e-4 apart
+        exp = [fi[p] for p in order]
+        es_ = np.array([ms[p] for p in order])
+        for a in range(10):
+            if (a == 0 or es_[a - 1] - es_[a] > 2e-4) and (a == 9 or es_[a] - es_[a + 1] > 2e-4):
+                assert got[a] == exp[a]
+
+
+def test_gather_topk_over_rccl_single_rank(T):
+    """The ``nccl`` (= RCCL) branch of the exchange -- all_gather_into_tensor on device tensors --
+    run with a 1-rank process group on this GPU, merge included."""
+    import os
+    import torch.distributed as dist
+    from triple_hybrid_rag_amd.distributed import ShardedIndex, gather_rows, gather_topk
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        x, rng = rand_docs(20000, 768, 3)
+        q = rng.standard_normal((40, 768)).astype(np.float32)
+        idx = T.GpuIndex(doc_base=1000).set_dense(x)
+        S, I, cnt, _ = idx.dense_search(dev(q), 100)
+        Sg, Ig = gather_topk(S, I)
+        torch.cuda.synchronize()
+        assert Sg.shape == (1, 40, 100) and torch.equal(Sg[0], S) and torch.equal(Ig[0], I)
+        Sm, Im, cm = T._native.merge_topk(Sg, Ig, 100)
+        assert torch.equal(Im, I) and torch.equal(Sm, S)
+        r = gather_rows(S.to(torch.float32))
+        assert r.shape == (1, 40, 100) and torch.equal(r[0], S.to(torch.float32))
+        # world == 1 through ShardedIndex's own code path as well
+        sh = ShardedIndex(idx)
+        sh.world = 2                      # force the exchange although the group has one rank
+        Sx, Ix = sh._merge(S, I, 100)
+        assert torch.equal(Ix, I)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_dense_f16_rows_outside_half_range(T):

@@ -60,11 +60,12 @@ _SIGNATURES = {
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
                              _i32, _i32, _vp, _vp, _vp, _vp]),
-    "thr_graph_workspace_bytes": (_sz, [_i32]),
-    "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32,
-                              _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "thr_graph_workspace_bytes": (_sz, [_i32, _i64]),
+    "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32,
+                              _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_rrf_fuse": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
                             _vp, _vp, _vp, _vp, _vp]),
+    "thr_rerank_order": (_i32, [_vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "thr_maxsim_pack": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -355,7 +356,9 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
 
 # --------------------------------------------------------------------- a4
 def graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, query_seeds, hops: int,
-               k: int, chunk_base: int, n_chunks: int):
+               k: int, chunk_base: int, n_chunks: int, transposed=None):
+    """-> (scores, ids, counts, flags).  ``transposed`` = (tmen_rowptr i64 [n_chunks+1], tmen_ent
+    i32, tmen_conf f32) from ``graph_transpose_mentions`` enables the capacity-free third tier."""
     per = _dev(ent_rowptr, torch.int64, "ent_rowptr", 1)
     pec = _dev(ent_col, torch.int32, "ent_col", 1)
     pmr = _dev(men_rowptr, torch.int64, "men_rowptr", 1)
@@ -364,17 +367,42 @@ def graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, query_seeds
     pqs = _dev(query_seeds, torch.int32, "query_seeds", 2)
     if ent_rowptr.shape != men_rowptr.shape or men_chunk.shape != men_conf.shape:
         raise NativeError("graph: CSR arrays are inconsistent")
+    ptr = pte = ptw = None
+    n_ent = ent_rowptr.shape[0] - 1
+    if transposed is not None:
+        tr, te, tw = transposed
+        ptr, pte, ptw = (_dev(tr, torch.int64, "tmen_rowptr", 1), _dev(te, torch.int32, "tmen_ent", 1),
+                         _dev(tw, torch.float32, "tmen_conf", 1))
+        if tr.shape[0] != n_chunks + 1 or te.shape != tw.shape:
+            raise NativeError("graph: transposed mention CSR is inconsistent")
     nq, ms = query_seeds.shape
     if ms > THR_GRAPH_MAX_SEEDS or k > THR_TOPK_MAX:
         raise NativeError("graph: too many seeds per query or k too large")
-    need = int(load().thr_graph_workspace_bytes(nq))
+    need = int(load().thr_graph_workspace_bytes(nq, n_ent if transposed is not None else 0))
     ws = torch.empty(max(need, 8), dtype=torch.uint8, device=ent_rowptr.device)
     S, I, cnt, flg = _alloc_out(nq, k, ent_rowptr.device)
-    _check(load().thr_graph_topk(per, pec, ent_rowptr.shape[0] - 1, pmr, pmc, pmw, chunk_base,
+    _check(load().thr_graph_topk(per, pec, n_ent, pmr, pmc, pmw, ptr, pte, ptw, chunk_base,
                                  n_chunks, pqs, nq, ms, hops, k, S.data_ptr(), I.data_ptr(),
                                  cnt.data_ptr(), flg.data_ptr(), ws.data_ptr(), need, _stream()),
            "thr_graph_topk")
     return S, I, cnt, flg
+
+
+def graph_transpose_mentions(men_rowptr, men_chunk, men_conf, chunk_base: int, n_chunks: int):
+    """Index set-up (device tensors, torch ops): the entity-major mention CSR restricted to this
+    shard's chunks, re-sorted chunk-major with a STABLE sort, so a chunk's entries stay in
+    (entity asc, mention) order -- the oracle's summation order."""
+    ne = men_rowptr.shape[0] - 1
+    ent = torch.repeat_interleave(torch.arange(ne, dtype=torch.int32, device=men_rowptr.device),
+                                  (men_rowptr[1:] - men_rowptr[:-1]))
+    local = men_chunk.to(torch.int64) - chunk_base
+    keep = (local >= 0) & (local < n_chunks)
+    ent, conf, local = ent[keep], men_conf[keep], local[keep]
+    order = torch.sort(local, stable=True).indices
+    counts = torch.bincount(local, minlength=n_chunks)
+    rowptr = torch.zeros(n_chunks + 1, dtype=torch.int64, device=men_rowptr.device)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    return rowptr, ent[order].contiguous(), conf[order].contiguous()
 
 
 # ----------------------------------------------------------------- a5 + a6
@@ -433,6 +461,26 @@ def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor,
     _check(load().thr_maxsim(pq, nq, qt, pdt, nd, dt, td, pc, cand.shape[1], out.data_ptr(),
                              1 if packed else 0, _stream()), "thr_maxsim")
     return out
+
+
+def rerank_order(scores: torch.Tensor, ids: torch.Tensor, counts: Optional[torch.Tensor], top_k: int):
+    """scores f32 [nq, n] or [n_lists, nq, n] (per-shard MaxSim lists: -inf where the shard does
+    not own the candidate) -> (ids i64 [nq, top_k], scores f64 [nq, top_k], counts i32 [nq]):
+    the reference's stable descending sort on ``rerank_score or 0`` (retrieval.py:455)."""
+    if scores.dim() == 2:
+        scores = scores.unsqueeze(0)
+    ps = _dev(scores, torch.float32, "scores", 3)
+    pi = _dev(ids, torch.int64, "ids", 2)
+    pc = _dev(counts, torch.int32, "counts", 1) if counts is not None else None
+    nl, nq, n = scores.shape
+    if tuple(ids.shape) != (nq, n):
+        raise NativeError("rerank_order: ids shape != scores shape")
+    out_ids = torch.empty((nq, top_k), dtype=torch.int64, device=ids.device)
+    out_s = torch.empty((nq, top_k), dtype=torch.float64, device=ids.device)
+    out_c = torch.empty(nq, dtype=torch.int32, device=ids.device)
+    _check(load().thr_rerank_order(ps, nl, nq * n, pi, pc, nq, n, top_k, out_ids.data_ptr(),
+                                   out_s.data_ptr(), out_c.data_ptr(), _stream()), "thr_rerank_order")
+    return out_ids, out_s, out_c
 
 
 # ------------------------------------------------------------- multi-GPU

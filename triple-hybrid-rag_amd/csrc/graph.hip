@@ -251,21 +251,123 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Third tier: queries that overflow the full on-chip capacities too (a hub entity with tens of
+// thousands of edges) are walked in GLOBAL memory -- no capacity left to overflow, so
+// THR_FLAG_OVERFLOW never reaches the caller and nothing in a batch pipeline has to raise.
+// GR_FB_BLOCKS workgroups share the overflowed queries of the batch; each owns one distance
+// array (1 byte per entity, 0xFF = not reached) and
+//   1. BFS, level-synchronous, by SCANNING the distance array for the entities of the previous
+//      level (no frontier lists); a wave expands one frontier entity at a time, lanes over its
+//      edges.  The distance bytes are read with L1-bypassing loads (the array is rewritten level
+//      after level by the same CU) and only ever change 0xFF -> level, so racing writers agree;
+//   2. scores every chunk of the shard from the TRANSPOSED mention CSR (chunk -> (entity, conf),
+//      in (entity asc, mention) order -- built once at index set-up): one thread per chunk sums
+//      conf/(1+dist) left to right in float64, which is the oracle's order, then the streaming
+//      block top-k.  O(E + mentions) per query instead of O(reached): a rare, slow, exact path.
+// ---------------------------------------------------------------------------------------------
+constexpr int GR_FB_BLOCKS = 16;
+
+__device__ __forceinline__ uint32_t gr_dist(const uint8_t* dist, uint32_t e) {
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(dist) + (e >> 2),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (w >> (8 * (e & 3))) & 0xffu;
+}
+
+__global__ __launch_bounds__(GR_THREADS) void graph_fallback_kernel(
+    const int64_t* __restrict__ ent_rowptr, const int32_t* __restrict__ ent_col, int64_t n_entities,
+    const int64_t* __restrict__ tmen_rowptr, const int32_t* __restrict__ tmen_ent,
+    const float* __restrict__ tmen_conf, int64_t chunk_base, int64_t n_chunks,
+    const int32_t* __restrict__ query_seeds, int n_queries, int max_seeds, int hops, int k,
+    uint8_t* __restrict__ dist_ws, int64_t e_pad, double* __restrict__ out_s,
+    int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt, uint32_t* __restrict__ out_flags) {
+    __shared__ double b_s[GrFull::CAP];
+    __shared__ int64_t b_id[GrFull::CAP];
+    __shared__ int b_cnt;
+    __shared__ double th_s;
+    __shared__ int64_t th_id;
+    uint8_t* dist = dist_ws + (int64_t)blockIdx.x * e_pad;
+    const int lane = threadIdx.x & 63;
+    for (int q = blockIdx.x; q < n_queries; q += gridDim.x) {
+        if (!(out_flags[q] & THR_FLAG_OVERFLOW)) continue;   // same answer in every thread
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < e_pad / 4; i += GR_THREADS)
+            reinterpret_cast<uint32_t*>(dist)[i] = 0xffffffffu;
+        __syncthreads();
+        if (threadIdx.x < max_seeds) {
+            const int32_t e = query_seeds[(int64_t)q * max_seeds + threadIdx.x];
+            if (e >= 0 && e < n_entities) dist[e] = 0;
+        }
+        __syncthreads();
+        for (int lvl = 1; lvl <= hops; ++lvl) {
+            for (int64_t base = 0; base < n_entities; base += GR_THREADS) {
+                const int64_t e = base + threadIdx.x;
+                const bool in_frontier = e < n_entities && gr_dist(dist, (uint32_t)e) == (uint32_t)(lvl - 1);
+                uint64_t m = __ballot(in_frontier);
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int64_t f = base + (threadIdx.x & ~63) + src;
+                    const int64_t lo = ent_rowptr[f], hi = ent_rowptr[f + 1];
+                    for (int64_t j = lo + lane; j < hi; j += WAVE) {
+                        const int32_t t = ent_col[j];
+                        if (t >= 0 && t < n_entities && gr_dist(dist, (uint32_t)t) == 0xffu)
+                            dist[t] = (uint8_t)lvl;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        BlockTopK<GrFull::CAP> tk;
+        tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);
+        for (int64_t base = 0; base < n_chunks; base += GR_THREADS) {
+            const int64_t c = base + threadIdx.x;
+            bool any = false;
+            double score = 0.0;
+            if (c < n_chunks) {
+                const int64_t lo = tmen_rowptr[c], hi = tmen_rowptr[c + 1];
+                for (int64_t j = lo; j < hi; ++j) {
+                    const uint32_t d = gr_dist(dist, (uint32_t)tmen_ent[j]);
+                    if (d != 0xffu) {
+                        score = __dadd_rn(score, __ddiv_rn((double)tmen_conf[j], __dadd_rn(1.0, (double)d)));
+                        any = true;
+                    }
+                }
+            }
+            tk.push(any, score, c);
+        }
+        const int n = tk.finish();
+        for (int i = threadIdx.x; i < k; i += GR_THREADS) {
+            out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
+            out_id[(int64_t)q * k + i] = i < n ? b_id[i] + chunk_base : -1;
+        }
+        if (threadIdx.x == 0) {
+            out_cnt[q] = n;
+            out_flags[q] = THR_FLAG_CERTIFIED | THR_FLAG_EXACT;
+        }
+    }
+}
+
 }  // namespace thr
 
 using namespace thr;
 
-extern "C" size_t thr_graph_workspace_bytes(int n_queries) {
-    return n_queries > 0 ? (size_t)n_queries * GR_MAX_CON * sizeof(double) : 0;
+static size_t graph_dist_pad(int64_t n_entities) { return (size_t)((n_entities + 255) / 256 * 256); }
+
+extern "C" size_t thr_graph_workspace_bytes(int n_queries, int64_t n_entities) {
+    if (n_queries <= 0) return 0;
+    return (size_t)n_queries * GR_MAX_CON * sizeof(double) +
+           (n_entities > 0 ? (size_t)GR_FB_BLOCKS * graph_dist_pad(n_entities) : 0);
 }
 
 extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col, int64_t n_entities,
                               const int64_t* men_rowptr, const int32_t* men_chunk,
-                              const float* men_conf, int64_t chunk_base, int64_t n_chunks,
-                              const int32_t* query_seeds, int n_queries, int max_seeds, int hops,
-                              int k, double* out_scores, int64_t* out_ids, int32_t* out_counts,
-                              uint32_t* out_flags, void* workspace, size_t workspace_bytes,
-                              thr_stream_t stream) {
+                              const float* men_conf, const int64_t* tmen_rowptr,
+                              const int32_t* tmen_ent, const float* tmen_conf, int64_t chunk_base,
+                              int64_t n_chunks, const int32_t* query_seeds, int n_queries,
+                              int max_seeds, int hops, int k, double* out_scores, int64_t* out_ids,
+                              int32_t* out_counts, uint32_t* out_flags, void* workspace,
+                              size_t workspace_bytes, thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!ent_rowptr || !ent_col || !men_rowptr || !men_chunk || !men_conf ||
                       !query_seeds || !out_scores || !out_ids || !out_counts || !out_flags ||
@@ -276,7 +378,9 @@ extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col,
                       max_seeds > THR_GRAPH_MAX_SEEDS || hops < 0 || hops > 8 || k <= 0 ||
                       k > THR_TOPK_MAX,
                   THR_ERR_INVALID);
-    THR_RETURN_IF(workspace_bytes < thr_graph_workspace_bytes(n_queries), THR_ERR_WORKSPACE);
+    const bool fallback = tmen_rowptr && tmen_ent && tmen_conf;
+    THR_RETURN_IF(workspace_bytes < thr_graph_workspace_bytes(n_queries, fallback ? n_entities : 0),
+                  THR_ERR_WORKSPACE);
     hipLaunchKernelGGL((graph_topk_kernel<GrSmall, false>), dim3(n_queries), dim3(GR_THREADS), 0,
                        (hipStream_t)stream, ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk,
                        men_conf, chunk_base, n_chunks, query_seeds, max_seeds, hops, k,
@@ -287,5 +391,13 @@ extern "C" int thr_graph_topk(const int64_t* ent_rowptr, const int32_t* ent_col,
                        (hipStream_t)stream, ent_rowptr, ent_col, n_entities, men_rowptr, men_chunk,
                        men_conf, chunk_base, n_chunks, query_seeds, max_seeds, hops, k,
                        (double*)workspace, out_scores, out_ids, out_counts, out_flags);
+    rc = launch_status();
+    if (rc || !fallback) return rc;
+    uint8_t* dist_ws = (uint8_t*)workspace + (size_t)n_queries * GR_MAX_CON * sizeof(double);
+    hipLaunchKernelGGL(graph_fallback_kernel, dim3(GR_FB_BLOCKS), dim3(GR_THREADS), 0,
+                       (hipStream_t)stream, ent_rowptr, ent_col, n_entities, tmen_rowptr, tmen_ent,
+                       tmen_conf, chunk_base, n_chunks, query_seeds, n_queries, max_seeds, hops, k,
+                       dist_ws, (int64_t)graph_dist_pad(n_entities), out_scores, out_ids, out_counts,
+                       out_flags);
     return launch_status();
 }

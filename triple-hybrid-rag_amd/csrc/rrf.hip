@@ -120,9 +120,65 @@ __global__ __launch_bounds__(RRF_THREADS) void rrf_fuse_kernel(
     if (t == 0) out_counts[q] = n < top_k ? n : top_k;
 }
 
+// Rerank ordering (retrieval.py:449-455): every candidate carries ONE rerank score -- the maximum
+// over n_lists score lists, of which exactly one holds a finite value when the lists are the
+// per-shard MaxSim outputs of a document-sharded index (the owning shard scored the candidate,
+// the others wrote -inf) -- and the candidates are stably sorted by ``rerank_score or 0``
+// descending: a candidate nobody scored counts as 0.0, ties keep the fused order.  One workgroup
+// per query, rank sort in LDS (n <= RRF_SLOTS).
+__global__ __launch_bounds__(RRF_THREADS) void rerank_order_kernel(
+    const float* __restrict__ scores, int n_lists, int64_t list_stride,
+    const int64_t* __restrict__ ids, const int32_t* __restrict__ counts, int n, int top_k,
+    int64_t* __restrict__ out_ids, double* __restrict__ out_scores, int32_t* __restrict__ out_counts) {
+    __shared__ double s_s[RRF_SLOTS];
+    __shared__ int order[RRF_SLOTS];
+    const int q = blockIdx.x, t = threadIdx.x;
+    int cnt = counts ? counts[q] : n;
+    cnt = cnt < n ? cnt : n;
+    for (int p = t; p < cnt; p += RRF_THREADS) {
+        float best = -INFINITY;
+        for (int l = 0; l < n_lists; ++l) best = fmaxf(best, scores[(int64_t)l * list_stride + (int64_t)q * n + p]);
+        s_s[p] = best > -INFINITY ? (double)best : 0.0;   // ``rerank_score or 0``
+    }
+    __syncthreads();
+    for (int p = t; p < cnt; p += RRF_THREADS) {
+        const double ms = s_s[p];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const double o = s_s[j];
+            rank += (o > ms || (o == ms && j < p)) ? 1 : 0;
+        }
+        order[rank] = p;
+    }
+    __syncthreads();
+    for (int i = t; i < top_k; i += RRF_THREADS) {
+        const bool ok = i < cnt;
+        const int p = ok ? order[i] : 0;
+        out_ids[(int64_t)q * top_k + i] = ok ? ids[(int64_t)q * n + p] : -1;
+        out_scores[(int64_t)q * top_k + i] = ok ? s_s[p] : -INFINITY;
+    }
+    if (t == 0) out_counts[q] = cnt < top_k ? cnt : top_k;
+}
+
 }  // namespace thr
 
 using namespace thr;
+
+extern "C" int thr_rerank_order(const float* scores, int n_lists, int64_t list_stride,
+                                const int64_t* ids, const int32_t* counts, int n_queries, int n,
+                                int top_k, int64_t* out_ids, double* out_scores,
+                                int32_t* out_counts, thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!scores || !ids || !out_ids || !out_scores || !out_counts, THR_ERR_INVALID);
+    THR_RETURN_IF(n_queries <= 0 || n_lists <= 0 || n <= 0 || n > RRF_SLOTS || top_k <= 0 || top_k > n,
+                  THR_ERR_INVALID);
+    if (list_stride == 0) list_stride = (int64_t)n_queries * n;
+    THR_RETURN_IF(list_stride < (int64_t)n_queries * n, THR_ERR_INVALID);
+    hipLaunchKernelGGL(rerank_order_kernel, dim3(n_queries), dim3(RRF_THREADS), 0, (hipStream_t)stream,
+                       scores, n_lists, list_stride, ids, counts, n, top_k, out_ids, out_scores,
+                       out_counts);
+    return launch_status();
+}
 
 extern "C" int thr_rrf_fuse(const int64_t* lex_ids, int n_lex, const int64_t* sem_ids, int n_sem,
                             const int64_t* graph_ids, int n_graph, int n_queries, double w_lex,

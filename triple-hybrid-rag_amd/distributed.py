@@ -80,6 +80,20 @@ def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
     return out[:, 0].view(torch.float64), out[:, 1]
 
 
+def gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather one fixed-shape tensor per rank -> [world, *x.shape] (the second exchange of
+    the rerank leg: each rank's [nq, n] MaxSim scores, -inf where it does not own the doc)."""
+    world = dist.get_world_size(group)
+    x = x.contiguous()
+    if dist.get_backend(group) == "gloo":
+        host = [torch.empty(x.shape, dtype=x.dtype) for _ in range(world)]
+        dist.all_gather(host, x.cpu(), group=group)
+        return torch.stack(host).to(x.device)
+    out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out
+
+
 class ShardedIndex:
     """A GpuIndex holding this rank's document shard + the cross-rank merge."""
 
@@ -97,18 +111,35 @@ class ShardedIndex:
 
     def retrieve_batch(self, queries, query_terms=None, query_seeds=None, top_k: int = 10,
                        semantic_top_k: int = 100, lexical_top_k: int = 50, graph_top_k: int = 50,
-                       weights: Optional[Dict[str, float]] = None, hops: int = 2) -> BatchResult:
+                       weights: Optional[Dict[str, float]] = None, hops: int = 2,
+                       qtok: Optional[torch.Tensor] = None, rerank_top_k: int = 100) -> BatchResult:
+        """Per channel: this shard's exact top-k -> all-gather -> merge; fusion on every rank (the
+        merged lists are identical everywhere); rerank: every rank scores the fused
+        candidates it OWNS with thr_maxsim (-inf for the others), a second all-gather of the
+        [nq, rerank_top_k] float32 scores, then thr_rerank_order takes the maximum per candidate
+        and applies the reference's stable sort."""
         w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
         w.update(weights or {})
         L = self.local
+        ch = {}
         Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False)
         Ss, Is = self._merge(Ss, Is, semantic_top_k)
+        ch["semantic"] = (Ss, Is, None)
         Il = Ig = None
         if query_terms is not None and L.lex is not None:
             Sl, Il, _ = L.bm25_search(query_terms, lexical_top_k)
             Sl, Il = self._merge(Sl, Il, lexical_top_k)
+            ch["lexical"] = (Sl, Il, None)
         if query_seeds is not None and L.graph is not None:
             Sg, Ig, _ = L.graph_search(query_seeds, graph_top_k, hops)
             Sg, Ig = self._merge(Sg, Ig, graph_top_k)
-        ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, top_k, w["lexical"], w["semantic"], w["graph"])
-        return BatchResult(ids, sc, cnt, {"semantic": (Ss, Is, None)}, nres)
+            ch["graph"] = (Sg, Ig, None)
+        rerank = qtok is not None and L.tokens is not None
+        n_fused = max(rerank_top_k, top_k) if rerank else top_k
+        ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, n_fused, w["lexical"], w["semantic"], w["graph"])
+        if rerank:
+            ms = L.maxsim(qtok, ids)
+            if self.world > 1:
+                ms = gather_rows(ms, self.group)
+            ids, sc, cnt = N.rerank_order(ms, ids, cnt, top_k)
+        return BatchResult(ids, sc, cnt, ch, nres)

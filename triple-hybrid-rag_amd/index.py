@@ -124,6 +124,16 @@ class GpuIndex:
                           men_conf=self._t(men_conf, torch.float32))
         return self
 
+    def _graph_transposed(self):
+        """Chunk-major copy of this shard's mentions (the capacity-free third tier of
+        thr_graph_topk), built on first use: the shard's chunk count must be known."""
+        G = self.graph
+        if G.get("n_chunks") != self.n_docs:
+            G["n_chunks"] = self.n_docs
+            G["transposed"] = N.graph_transpose_mentions(G["men_rowptr"], G["men_chunk"],
+                                                         G["men_conf"], self.doc_base, self.n_docs)
+        return G["transposed"]
+
     def set_tokens(self, dtok, pack: bool = True) -> "GpuIndex":
         """Late-interaction token store f16 [n, d_tokens, tok_dim].  pack=True keeps it in the
         fragment-major layout of thr_maxsim_pack (the row-major copy is dropped)."""
@@ -202,12 +212,12 @@ class GpuIndex:
 
     def graph_search(self, query_seeds: torch.Tensor, k: int, hops: int = 2):
         G = self.graph
-        S, I, cnt, flg = N.graph_topk(G["ent_rowptr"], G["ent_col"], G["men_rowptr"],
-                                      G["men_chunk"], G["men_conf"],
-                                      self._t(query_seeds, torch.int32), hops, k, self.doc_base,
-                                      self.n_docs)
-        if bool(((flg & N.THR_FLAG_OVERFLOW) != 0).any()):
-            raise N.NativeError("graph walk exceeded its on-chip capacity for some query")
+        # three tiers on the device (small / full on-chip capacities, then a capacity-free walk
+        # in global memory): no flag to read back, nothing to raise in the middle of a batch
+        S, I, cnt, _ = N.graph_topk(G["ent_rowptr"], G["ent_col"], G["men_rowptr"],
+                                    G["men_chunk"], G["men_conf"],
+                                    self._t(query_seeds, torch.int32), hops, k, self.doc_base,
+                                    self.n_docs, transposed=self._graph_transposed())
         return S, I, cnt
 
     def maxsim(self, qtok: torch.Tensor, cand_global_ids: torch.Tensor) -> torch.Tensor:
@@ -239,12 +249,11 @@ class GpuIndex:
         if query_seeds is not None and self.graph is not None:
             Sg, Ig, Cg = self.graph_search(query_seeds, graph_top_k, hops)
             ch["graph"] = (Sg, Ig, Cg)
-        n_fused = rerank_top_k if qtok is not None else top_k
+        rerank = qtok is not None and self.tokens is not None
+        n_fused = max(rerank_top_k, top_k) if rerank else top_k
         ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, n_fused, w["lexical"], w["semantic"], w["graph"])
-        if qtok is not None and self.tokens is not None:
-            ms = self.maxsim(qtok, ids).to(torch.float64)
-            # stable descending sort on the rerank score (retrieval.py:455)
-            order = torch.sort(ms, dim=1, descending=True, stable=True).indices[:, :top_k]
-            ids, sc = torch.gather(ids, 1, order), torch.gather(ms, 1, order)
-            cnt = torch.clamp(cnt, max=top_k)
+        if rerank:
+            # MaxSim of the fused top rerank_top_k, then the reference's stable descending sort
+            # on ``rerank_score or 0`` (retrieval.py:449-455), on the device
+            ids, sc, cnt = N.rerank_order(self.maxsim(qtok, ids), ids, cnt, top_k)
         return BatchResult(ids, sc, cnt, ch, nres)
