@@ -86,9 +86,15 @@ int thr_doc_norms(const float *docs, int64_t n_docs, int dim, double *dnorm, flo
  * top-k exact; otherwise call thr_dense_topk_exact for that query.
  * Outputs are padded with (-inf, -1) beyond out_counts[q]. */
 size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queries, int kprime);
+/* Collection filter of the RPC (``AND (p_collection IS NULL OR d.collection = p_collection)``,
+ * rag2_schema.sql:404-408), applied BEFORE the ranking on the device: doc_coll int32 [n_docs]
+ * (any labelling) and query_coll int32 [nq] (-1 = unfiltered) -- both or neither (NULL).  The
+ * threshold sample, the shortlist and the exhaustive path all see only rows of the query's
+ * collection; a collection too thin for the sampled threshold ends on the exhaustive path. */
 int thr_dense_topk(const float *docs, const double *dnorm, const float *inv_norm, int64_t n_docs,
                    int dim, int64_t id_base, const float *queries, int n_queries, int k,
-                   int kprime, double *out_scores /* [nq,k] */, int64_t *out_ids /* [nq,k] */,
+                   int kprime, const int32_t *doc_coll, const int32_t *query_coll,
+                   double *out_scores /* [nq,k] */, int64_t *out_ids /* [nq,k] */,
                    int32_t *out_counts /* [nq] */, uint32_t *out_flags /* [nq] */,
                    void *workspace, size_t workspace_bytes, thr_stream_t stream);
 
@@ -97,6 +103,7 @@ int thr_dense_topk(const float *docs, const double *dnorm, const float *inv_norm
 size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries);
 int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs, int dim,
                          int64_t id_base, const float *queries, int n_queries, int k,
+                         const int32_t *doc_coll, const int32_t *query_coll,
                          double *out_scores, int64_t *out_ids, int32_t *out_counts,
                          uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                          thr_stream_t stream);
@@ -108,6 +115,7 @@ int thr_dense_topk_exact(const float *docs, const double *dnorm, int64_t n_docs,
 size_t thr_dense_rescue_workspace_bytes(int n_queries, int k);
 int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int dim,
                      int64_t id_base, const float *queries, int n_queries, int k,
+                     const int32_t *doc_coll, const int32_t *query_coll,
                      double *io_scores, int64_t *io_ids, int32_t *io_counts, uint32_t *io_flags,
                      int32_t *n_rescued, void *workspace, size_t workspace_bytes,
                      thr_stream_t stream);
@@ -141,6 +149,7 @@ size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries, int
 int thr_dense_topk_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
                        const double *dnorm, const float *inv_norm, int64_t n_docs, int dim,
                        int64_t id_base, const float *queries, int n_queries, int k, int kprime,
+                       const int32_t *doc_coll, const int32_t *query_coll,
                        double *out_scores, int64_t *out_ids, int32_t *out_counts,
                        uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                        thr_stream_t stream);
@@ -171,12 +180,30 @@ int thr_dense_scan_probe(const float *docs, const float *inv_norm, int64_t n_doc
  * LIMIT k) is called, rag2_schema.sql:341-374 / retrieval.py:282-290; the
  * north-star mandates BM25 in its place.  ``query_terms`` is [nq, max_terms]
  * term ids, negative = padding.  idf[] and avgdl are corpus-GLOBAL. */
+/* Index set-up: upper bounds for the WAND-style pruning of thr_bm25_topk, computed with the
+ * scoring formula itself: term_ub[t] = max contribution of a posting of term t, block_ub[j] = max
+ * contribution among postings [128 j, 128 j + 128) of the posting array
+ * (thr_bm25_block_count(nnz) doubles).  They depend on idf / avgdl / k1 / b. */
+size_t thr_bm25_block_count(int64_t nnz);
+int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_t *post_tf,
+                    const float *doclen, const double *idf, double avgdl, double k1, double b,
+                    int64_t n_vocab, int64_t nnz, double *term_ub /* [V] */,
+                    double *block_ub /* [thr_bm25_block_count(nnz)] */, thr_stream_t stream);
+/* term ids outside [0, n_vocab) are ignored (no postings).  term_ub / block_ub (or NULL: score
+ * every posting): a doc whose bound cannot beat the running k-th best score is dropped before its
+ * term frequencies are fetched -- same results, bit for bit.  conjunctive != 0: only docs that
+ * hold EVERY query term (the reference's plainto_tsquery is an AND, rag2_schema.sql:365; the
+ * oracle's and north star's BM25 is the OR form, the default).  doc_coll [n_docs] / query_coll
+ * [nq] (both or neither; query_coll -1 = unfiltered): only docs of the query's collection are
+ * ranked, BEFORE the top-k -- ``AND (p_collection IS NULL OR d.collection = p_collection)``,
+ * rag2_schema.sql:368-373. */
 int thr_bm25_topk(const int64_t *rowptr /* [V+1] */, const int32_t *post_doc,
                   const int32_t *post_tf, const float *doclen /* [n_docs] */,
-                  const double *idf /* [V] */, double avgdl, double k1, double b,
-                  int64_t n_docs, int64_t id_base, const int32_t *query_terms, int n_queries,
-                  int max_terms, int k, double *out_scores, int64_t *out_ids,
-                  int32_t *out_counts, thr_stream_t stream);
+                  const double *idf /* [V] */, const double *term_ub, const double *block_ub,
+                  double avgdl, double k1, double b, int64_t n_docs, int64_t n_vocab,
+                  int64_t id_base, const int32_t *query_terms, int n_queries, int max_terms, int k,
+                  int conjunctive, const int32_t *doc_coll, const int32_t *query_coll,
+                  double *out_scores, int64_t *out_ids, int32_t *out_counts, thr_stream_t stream);
 
 /* a4  graph channel: bounded BFS (<= hops) from seed entities over the
  * entity CSR, then score(chunk) = sum_e conf(e,chunk)/(1+dist(e)) over the

@@ -254,6 +254,128 @@ def test_bm25_matches_oracle(T):
     assert int(cnt[3]) == 0
 
 
+def test_bm25_pruning_and_filters_stay_exact(T):
+    """The WAND-style pruning (term / block score bounds), the conjunctive mode, the collection
+    filter and an out-of-vocabulary term id: each equals the oracle bit for bit -- also on
+    queries made of the longest lists (stop words), where almost every doc is dropped on its
+    bound."""
+    from triple_hybrid_rag_amd import synth
+    n = 60000
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    idx = T.GpuIndex().set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+    coll = (np.arange(n) * 7919 % 50).astype(np.int32)          # 50 collections of 2 % each
+    coll[n // 2:] = np.where(np.arange(n - n // 2) % 2 == 0, 60, coll[n // 2:])   # + one fat one (25 %)
+    idx.set_collections(coll)
+    qt = synth.lexical_queries(48, csr.df_local, 4)               # sampled by df: stop words included
+    top = np.argsort(-csr.df_local)[:6].astype(np.int32)
+    qt[0] = top[:4]                                               # the four longest lists
+    qt[1] = [top[0], top[1], top[0], -1]                          # a repeated term, padding
+    qt[2] = [top[2], v + 5, 2 ** 30, -1]                          # ids outside the vocabulary: ignored
+    qt[3] = [-1, -1, -1, -1]                                      # no term at all
+    qd = dev(qt)
+    Se, Ie = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
+    for prune in (True, False):
+        S, I, cnt = idx.bm25_search(qd, 50, prune=prune)
+        assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"bm25 prune={prune}")
+    Sa, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
+                         conjunctive=True)
+    S, I, cnt = idx.bm25_search(qd, 50, conjunctive=True)
+    assert_topk_equal(S, I, cnt, Sa, Ia, [len(s) for s in Sa], "bm25 AND")
+    assert len(Ia[0]) > 0 and len(Ia[0]) <= len(Ie[0])
+    qc = np.full(48, -1, dtype=np.int32)
+    qc[0::3], qc[1::3] = 7, 60                                    # thin, fat, unfiltered
+    qc[5] = 12345                                                 # a collection no doc is in
+    Sf, If = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
+                         doc_coll=coll, query_coll=qc)
+    S, I, cnt = idx.bm25_search(qd, 50, collections=dev(qc))
+    assert_topk_equal(S, I, cnt, Sf, If, [len(s) for s in Sf], "bm25 collection")
+    assert len(If[5]) == 0 and all(coll[i] == 7 for i in If[0])
+
+
+@pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
+def test_dense_collection_filter_before_topk(T, shortlist):
+    """p_collection is a WHERE clause (rag2_schema.sql:404-408): the limit best rows OF THE
+    COLLECTION, however deep they sit in the unfiltered ranking.  A 2 % collection has ~0.4
+    members among the unfiltered top-20 and ~1.6 among the top-80 round 1 over-fetched."""
+    n, d, k = 60000, 768, 20
+    x, rng = rand_docs(n, d, 23)
+    x[77] = 0
+    coll = (np.arange(n) * 7919 % 50).astype(np.int32)
+    coll[n // 2:] = np.where(np.arange(n - n // 2) % 2 == 0, 60, coll[n // 2:])
+    q = rng.standard_normal((9, d)).astype(np.float32)
+    q[:4] = x[[5, 6000, 31000, 59999]] + 0.5 * q[:4]
+    qc = np.array([7, 60, -1, 7, 60, 12345, -1, 3, 60], dtype=np.int32)
+    idx = T.GpuIndex(doc_base=500).set_dense(x, shortlist=shortlist).set_collections(coll)
+    S, I, cnt, nres = idx.dense_search(dev(q), k, collections=dev(qc))
+    S, I, cnt = S.cpu().numpy(), I.cpu().numpy(), cnt.cpu().numpy()
+    dn = O.doc_norms_f64(x)
+    for i in range(9):
+        s = O.cosine_scores_f64(x, q[i], dn)
+        if qc[i] != -1:
+            s[coll != qc[i]] = -np.inf
+        ts, ti = O.topk_desc(s, k)
+        assert cnt[i] == len(ti) and np.array_equal(I[i, :len(ti)], ti + 500), (i, qc[i])
+        assert np.array_equal(S[i, :len(ti)], ts)
+    assert cnt[5] == 0
+    # the default scan applies the filter as it emits: even the 2 % collections stay on the
+    # shortlist path; the other flavours send them through the exhaustive one
+    assert nres == 0 if shortlist == "f16" else nres >= 1
+    unf = O.topk_desc(O.cosine_scores_f64(x, q[0], dn), 4 * k)[1]
+    assert np.sum(coll[unf] == 7) < k            # post-filtering an over-fetched list falls short
+    # the fat collection (25 % of the rows) is answered by the shortlist path, not the exhaustive
+    # one -- in the default scan, whose emit applies the filter; the other two flavours filter in
+    # select_rescore only, their shared tile lists overflow here and the exhaustive path answers
+    if shortlist != "f16":
+        return
+    fl = "f32" != shortlist
+    kp = 192 if fl else 128
+    args = (idx.docs, idx.dnorm, idx.inv_norm, dev(q), k, kp, 500)
+    S2, I2, c2, flg = (T._native.dense_topk_f16(idx.docs, idx.docs16, idx.doc_rel_err, *args[1:],
+                                                doc_coll=idx.doc_coll, query_coll=dev(qc)) if fl else
+                       T._native.dense_topk(*args, doc_coll=idx.doc_coll, query_coll=dev(qc)))
+    flg = flg.cpu().numpy()
+    assert all(flg[i] & 1 for i in (1, 2, 4, 6, 8))
+
+
+def test_backend_rpcs_filter_by_collection_on_device(T):
+    """The two RPCs with p_collection through the Supabase-shaped client."""
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    n, d = 30000, 768
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    store = CorpusStore.synthetic(n, vocab_size=v)
+    store.collections = [f"col{i * 7919 % 40}" if i % 11 else None for i in range(n)]
+    idx = T.GpuIndex().set_dense(x).set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+    client = GpuIndexClient(idx, store, org_id="org")
+    q = synth.dense_queries(2, d, n)
+    rows = client.rpc("rag2_semantic_search", {"p_org_id": "org", "p_embedding": q[0].tolist(),
+                                               "p_limit": 25, "p_collection": "col3"}).execute().data
+    assert len(rows) == 25 and all(store.collections[int(r["child_id"][1:])] == "col3" for r in rows)
+    mask = np.array([c == "col3" for c in store.collections])
+    s = O.cosine_scores_f64(x, q[0])
+    s[~mask] = -np.inf
+    ts, ti = O.topk_desc(s, 25)
+    assert [int(r["child_id"][1:]) for r in rows] == list(ti) and [r["similarity"] for r in rows] == list(ts)
+    top = np.argsort(-csr.df_local)[:3]
+    text = " ".join(f"t{t}" for t in top)
+    rows = client.rpc("rag2_lexical_search", {"p_org_id": "org", "p_query": text, "p_limit": 30,
+                                              "p_collection": "col3"}).execute().data
+    coll_id = np.array([1 if c == "col3" else 0 for c in store.collections], dtype=np.int32)
+    _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [list(top)], n, 30,
+                        doc_coll=coll_id, query_coll=[1])
+    assert [int(r["child_id"][1:]) for r in rows] == list(Il[0]) and len(rows) == 30
+    assert client.rpc("rag2_semantic_search", {"p_org_id": "org", "p_embedding": q[0].tolist(),
+                                               "p_limit": 5, "p_collection": "nope"}).execute().data == []
+    # the reference's lexical RPC is an AND over the query terms (plainto_tsquery): optional here
+    client_and = GpuIndexClient(idx, store, org_id="org", lexical_and=True)
+    rows_and = client_and.rpc("rag2_lexical_search", {"p_org_id": "org", "p_query": text, "p_limit": 30,
+                                                      "p_collection": None}).execute().data
+    _, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [list(top)], n, 30,
+                        conjunctive=True)
+    assert [int(r["child_id"][1:]) for r in rows_and] == list(Ia[0])
+
+
 def test_graph_matches_oracle(T):
     from triple_hybrid_rag_amd import synth
     n = 40000

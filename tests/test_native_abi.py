@@ -29,8 +29,13 @@ def test_library_exports_every_declared_symbol():
 def test_host_side_argument_checks_do_not_need_a_gpu():
     lib = T._native.load()
     # null pointers / bad sizes are rejected before any launch
-    assert lib.thr_dense_topk(None, None, None, 10, 768, 0, None, 1, 10, 128, None, None, None,
-                              None, None, 0, None) == -1
+    assert lib.thr_dense_topk(None, None, None, 10, 768, 0, None, 1, 10, 128, None, None, None, None,
+                              None, None, None, 0, None) == -1
+    # bm25: a vocabulary size is part of the call (term ids >= V are ignored, not dereferenced)
+    assert lib.thr_bm25_topk(None, None, None, None, None, None, None, 1.0, 1.2, 0.75, 10, 5, 0, None,
+                             1, 4, 10, 0, None, None, None, None, None, None) == -1
+    assert lib.thr_bm25_block_count(129) == 2 and lib.thr_bm25_block_count(0) == 0
+    assert lib.thr_graph_workspace_bytes(2, 1000) == 2 * 8192 * 8 + 16 * 1024
     assert lib.thr_dense_workspace_bytes(1_000_000, 768, 1024, 128) > 2 ** 20
     assert lib.thr_maxsim(None, 1, 32, None, 1, 128, 128, None, 1, None, 0, None) == -1
     assert lib.thr_rrf_fuse(None, 0, None, 0, None, 0, 1, 0.7, 0.8, 1.0, 60, 10, None, None, None,

@@ -41,25 +41,27 @@ _SIGNATURES = {
     "thr_embed_postproc": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "thr_doc_norms": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "thr_dense_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
-    "thr_dense_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _vp,
+    "thr_dense_topk": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_exact_workspace_bytes": (_sz, [_i64, _i32]),
-    "thr_dense_topk_exact": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp,
+    "thr_dense_topk_exact": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe": (_i32, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_rescue_workspace_bytes": (_sz, [_i32, _i32]),
-    "thr_dense_rescue": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+    "thr_dense_rescue": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _sz, _vp]),
     "thr_dense_quantize_f16": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "thr_dense_f16_copy_bytes": (_sz, [_i64, _i32]),
     "thr_dense_f16_query_tile": (_i32, [_i32, _i32, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
-                                  _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
-    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _i32,
-                             _i32, _i32, _vp, _vp, _vp, _vp]),
+    "thr_bm25_block_count": (_sz, [_i64]),
+    "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp]),
+    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64,
+                             _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32,
                               _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -171,8 +173,19 @@ def _alloc_out(nq: int, k: int, device):
             torch.empty(nq, dtype=torch.int32, device=device))
 
 
+def _coll(doc_coll, query_coll, n: int, nq: int):
+    """(doc_coll ptr, query_coll ptr) of the collection filter, or (None, None)."""
+    if query_coll is None:
+        return None, None
+    if doc_coll is None:
+        raise NativeError("query_coll without doc_coll")
+    if doc_coll.shape != (n,) or query_coll.shape != (nq,):
+        raise NativeError("doc_coll / query_coll have the wrong length")
+    return _dev(doc_coll, torch.int32, "doc_coll", 1), _dev(query_coll, torch.int32, "query_coll", 1)
+
+
 def dense_topk(docs, dnorm, inv_norm, queries, k: int, kprime: int, id_base: int = 0,
-               workspace: Optional[torch.Tensor] = None):
+               workspace: Optional[torch.Tensor] = None, doc_coll=None, query_coll=None):
     """-> (scores f64 [nq,k], ids i64 [nq,k], counts i32 [nq], flags i32 [nq])."""
     pd = _dev(docs, torch.float32, "docs", 2)
     n, d = docs.shape
@@ -189,14 +202,15 @@ def dense_topk(docs, dnorm, inv_norm, queries, k: int, kprime: int, id_base: int
         workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
     pw = _dev(workspace, workspace.dtype, "workspace")
     S, I, cnt, flg = _alloc_out(nq, k, docs.device)
-    _check(load().thr_dense_topk(pd, pn, pi, n, d, id_base, pq, nq, k, kprime, S.data_ptr(),
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
+    _check(load().thr_dense_topk(pd, pn, pi, n, d, id_base, pq, nq, k, kprime, pdc, pqc, S.data_ptr(),
                                  I.data_ptr(), cnt.data_ptr(), flg.data_ptr(), pw,
                                  workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_topk")
     return S, I, cnt, flg
 
 
-def dense_topk_exact(docs, dnorm, queries, k: int, id_base: int = 0):
+def dense_topk_exact(docs, dnorm, queries, k: int, id_base: int = 0, doc_coll=None, query_coll=None):
     pd = _dev(docs, torch.float32, "docs", 2)
     n, d = docs.shape
     pq = _dev(queries, torch.float32, "queries", 2)
@@ -209,7 +223,8 @@ def dense_topk_exact(docs, dnorm, queries, k: int, id_base: int = 0):
     need = int(load().thr_dense_exact_workspace_bytes(n, nq))
     ws = torch.empty(need, dtype=torch.uint8, device=docs.device)
     S, I, cnt, flg = _alloc_out(nq, k, docs.device)
-    _check(load().thr_dense_topk_exact(pd, pn, n, d, id_base, pq, nq, k, S.data_ptr(),
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
+    _check(load().thr_dense_topk_exact(pd, pn, n, d, id_base, pq, nq, k, pdc, pqc, S.data_ptr(),
                                        I.data_ptr(), cnt.data_ptr(), flg.data_ptr(),
                                        ws.data_ptr(), need, _stream()), "thr_dense_topk_exact")
     return S, I, cnt, flg
@@ -237,7 +252,7 @@ def dense_rescue_workspace_bytes(n_queries: int, k: int) -> int:
 
 
 def dense_rescue(docs, dnorm, queries, S, I, cnt, flg, id_base: int = 0,
-                 workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 workspace: Optional[torch.Tensor] = None, doc_coll=None, query_coll=None) -> torch.Tensor:
     """Redo, in place and without a host read-back, the queries of a dense_topk[_f16] result
     whose flags lack THR_FLAG_CERTIFIED.  -> device int32[1]: how many were redone."""
     pd = _dev(docs, torch.float32, "docs", 2)
@@ -249,7 +264,8 @@ def dense_rescue(docs, dnorm, queries, S, I, cnt, flg, id_base: int = 0,
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
     n_rescued = torch.zeros(1, dtype=torch.int32, device=docs.device)
-    _check(load().thr_dense_rescue(pd, pn, n, d, id_base, pq, nq, k, S.data_ptr(), I.data_ptr(),
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
+    _check(load().thr_dense_rescue(pd, pn, n, d, id_base, pq, nq, k, pdc, pqc, S.data_ptr(), I.data_ptr(),
                                    cnt.data_ptr(), flg.data_ptr(), n_rescued.data_ptr(),
                                    workspace.data_ptr(),
                                    workspace.numel() * workspace.element_size(), _stream()),
@@ -277,7 +293,8 @@ def dense_f16_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int
 
 
 def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k: int,
-                   kprime: int, id_base: int = 0, workspace: Optional[torch.Tensor] = None):
+                   kprime: int, id_base: int = 0, workspace: Optional[torch.Tensor] = None,
+                   doc_coll=None, query_coll=None):
     pd = _dev(docs, torch.float32, "docs", 2)
     ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
     n, d = docs.shape
@@ -296,8 +313,9 @@ def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k
         workspace = torch.empty(need, dtype=torch.uint8, device=docs.device)
     pw = _dev(workspace, workspace.dtype, "workspace")
     S, I, cnt, flg = _alloc_out(nq, k, docs.device)
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
     _check(load().thr_dense_topk_f16(pd, ph, float(doc_rel_err), pn, pi, n, d, id_base, pq, nq, k,
-                                     kprime, S.data_ptr(), I.data_ptr(), cnt.data_ptr(),
+                                     kprime, pdc, pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(),
                                      flg.data_ptr(), pw,
                                      workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_topk_f16")
@@ -334,8 +352,28 @@ def dense_scan_stamps_f16(docs16, n_docs: int, queries_n: int, workspace: torch.
 
 
 # --------------------------------------------------------------------- a3
+def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float = 1.2,
+                b: float = 0.75):
+    """Index set-up -> (term_ub f64 [V], block_ub f64 [ceil(nnz/128)]): the upper bounds
+    thr_bm25_topk prunes with."""
+    pr = _dev(rowptr, torch.int64, "rowptr", 1)
+    pdoc = _dev(post_doc, torch.int32, "post_doc", 1)
+    ptf = _dev(post_tf, torch.int32, "post_tf", 1)
+    pdl = _dev(doclen, torch.float32, "doclen", 1)
+    pidf = _dev(idf, torch.float64, "idf", 1)
+    v, nnz = idf.shape[0], post_doc.shape[0]
+    tub = torch.zeros(v, dtype=torch.float64, device=rowptr.device)
+    bub = torch.zeros(max(int(load().thr_bm25_block_count(nnz)), 1), dtype=torch.float64,
+                      device=rowptr.device)
+    if nnz:
+        _check(load().thr_bm25_bounds(pr, pdoc, ptf, pdl, pidf, avgdl, k1, b, v, nnz, tub.data_ptr(),
+                                      bub.data_ptr(), _stream()), "thr_bm25_bounds")
+    return tub, bub
+
+
 def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms, k: int,
-              id_base: int = 0, k1: float = 1.2, b: float = 0.75):
+              id_base: int = 0, k1: float = 1.2, b: float = 0.75, bounds=None,
+              conjunctive: bool = False, doc_coll=None, query_coll=None):
     pr = _dev(rowptr, torch.int64, "rowptr", 1)
     pdoc = _dev(post_doc, torch.int32, "post_doc", 1)
     ptf = _dev(post_tf, torch.int32, "post_tf", 1)
@@ -347,10 +385,23 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
     nq, mt = query_terms.shape
     if mt > THR_BM25_MAX_TERMS or k > THR_TOPK_MAX:
         raise NativeError("bm25: too many terms per query or k too large")
+    ptu = pbu = None
+    if bounds is not None:
+        ptu, pbu = _dev(bounds[0], torch.float64, "term_ub", 1), _dev(bounds[1], torch.float64, "block_ub", 1)
+        if bounds[0].shape[0] != idf.shape[0]:
+            raise NativeError("bm25: term_ub length != vocabulary size")
+    pdc = pqc = None
+    if query_coll is not None:
+        if doc_coll is None:
+            raise NativeError("bm25: query_coll without doc_coll")
+        pdc, pqc = _dev(doc_coll, torch.int32, "doc_coll", 1), _dev(query_coll, torch.int32, "query_coll", 1)
+        if doc_coll.shape[0] != doclen.shape[0] or query_coll.shape[0] != nq:
+            raise NativeError("bm25: doc_coll / query_coll have the wrong length")
     S, I, cnt, _ = _alloc_out(nq, k, rowptr.device)
-    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, avgdl, k1, b, doclen.shape[0], id_base,
-                                pqt, nq, mt, k, S.data_ptr(), I.data_ptr(), cnt.data_ptr(),
-                                _stream()), "thr_bm25_topk")
+    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, avgdl, k1, b, doclen.shape[0],
+                                idf.shape[0], id_base, pqt, nq, mt, k, 1 if conjunctive else 0, pdc,
+                                pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), _stream()),
+           "thr_bm25_topk")
     return S, I, cnt
 
 

@@ -121,11 +121,30 @@ class GpuIndexClient:
     """Supabase-shaped facade over (GpuIndex, CorpusStore)."""
 
     def __init__(self, index: GpuIndex, store: CorpusStore, org_id: Optional[str] = None,
-                 token_embedder: Any = None):
+                 token_embedder: Any = None, lexical_and: bool = False):
+        """lexical_and: rank only chunks holding EVERY query term, as the reference's
+        ``plainto_tsquery`` does (rag2_schema.sql:365); default is BM25's OR form, the
+        north star's and the oracle's."""
+        self.lexical_and = bool(lexical_and)
         self.index = index
         self.store = store
         self.org_id = org_id
         self.token_embedder = token_embedder
+        # collection names -> ids; the filter itself runs on the device, before the ranking
+        self._coll_id: Dict[str, int] = {}
+        if store.collections is not None:
+            names = sorted({c for c in store.collections if c is not None})
+            self._coll_id = {c: i for i, c in enumerate(names)}
+            if index.doc_coll is None:
+                index.set_collections(np.array([self._coll_id.get(c, -2) if c is not None else -2
+                                                for c in store.collections], dtype=np.int32))
+
+    def _qcoll(self, collection):
+        """int32 [1] collection id of a one-query call, None when unfiltered; a name no row
+        carries gets an id no row carries (empty result, as the SQL WHERE would give)."""
+        if collection is None or self.index.doc_coll is None:
+            return None
+        return torch.tensor([self._coll_id.get(collection, -3)], dtype=torch.int32, device=self.index.device)
 
     # ---------------------------------------------------------------- RPCs
     def rpc(self, name: str, params: Dict[str, Any]):
@@ -187,18 +206,12 @@ class GpuIndexClient:
             rows.append(row)
         return rows
 
-    def _rows(self, ids, scores, count, score_key, collection, limit):
+    def _rows(self, ids, scores, count, score_key, limit):
         out = []
-        for gid, sc in zip(ids[:count], scores[:count]):
-            i = int(gid) - self.store.doc_base
-            if collection is not None and self.store.collections is not None \
-                    and self.store.collections[i] != collection:
-                continue
-            row = self.store.result_row(i)
+        for gid, sc in zip(ids[:min(count, limit)], scores[:count]):
+            row = self.store.result_row(int(gid) - self.store.doc_base)
             row[score_key] = float(sc)
             out.append(row)
-            if len(out) == limit:
-                break
         return out
 
     def _semantic(self, embedding, limit: int, collection):
@@ -206,9 +219,9 @@ class GpuIndexClient:
                          device=self.index.device)
         if q.shape[1] != self.index.dim:
             raise ValueError(f"embedding has {q.shape[1]} dims, index has {self.index.dim}")
-        k = min(N.THR_DENSE_MAX_K, limit if collection is None else 4 * limit)
-        S, I, cnt, _ = self.index.dense_search(q, k)
-        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "similarity", collection, limit)
+        k = min(N.THR_DENSE_MAX_K, limit)
+        S, I, cnt, _ = self.index.dense_search(q, k, collections=self._qcoll(collection))
+        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "similarity", limit)
 
     def _lexical(self, query: str, limit: int, collection):
         terms: List[int] = []
@@ -220,9 +233,10 @@ class GpuIndexClient:
             return []
         terms = terms[: N.THR_BM25_MAX_TERMS]
         qt = torch.tensor([terms], dtype=torch.int32, device=self.index.device)
-        k = min(N.THR_TOPK_MAX, limit if collection is None else 2 * limit)
-        S, I, cnt = self.index.bm25_search(qt, k)
-        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "rank", collection, limit)
+        k = min(N.THR_TOPK_MAX, limit)
+        S, I, cnt = self.index.bm25_search(qt, k, collections=self._qcoll(collection),
+                                           conjunctive=self.lexical_and)
+        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "rank", limit)
 
     # -------------------------------------------------------------- tables
     def table(self, name: str) -> _TableQuery:

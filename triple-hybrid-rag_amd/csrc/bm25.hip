@@ -59,21 +59,67 @@ __device__ __forceinline__ double bm25_contrib(double idf, double tf, double dl,
     return __dmul_rn(idf, __ddiv_rn(__dmul_rn(tf, __dadd_rn(k1, 1.0)), __dadd_rn(tf, nrm)));
 }
 
+// Upper bounds for WAND-style pruning, computed once at index set-up (thr_bm25_bounds) with the
+// scoring formula itself: term_ub[t] = max over the postings of term t of bm25_contrib, and
+// block_ub[j] = the same maximum over postings [128 j, 128 j + 128) of the posting array (a block
+// that straddles two short lists bounds both).  Kept as order-preserving uint64 keys while the
+// atomicMax passes run, decoded in place by bm25_bounds_decode.
+constexpr int BM_BLOCK = 128;
+
+__global__ __launch_bounds__(256) void bm25_bounds_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
+    const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
+    const double* __restrict__ idf, double avgdl, double k1, double b, int64_t n_vocab, int64_t nnz,
+    unsigned long long* __restrict__ term_key, unsigned long long* __restrict__ block_key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nnz) return;
+    int64_t lo = 0, hi = n_vocab;  // last term with rowptr[t] <= i
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rowptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    const double c = bm25_contrib(idf[lo], (double)post_tf[i], (double)doclen[post_doc[i]], avgdl, k1, b);
+    const unsigned long long key = dkey(c);
+    atomicMax(&term_key[lo], key);
+    atomicMax(&block_key[i / BM_BLOCK], key);
+}
+__global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        // an untouched slot (term without postings) bounds nothing: 0
+        const double v = keys[i] ? dkey_inv(keys[i]) : 0.0;
+        reinterpret_cast<double*>(keys)[i] = v;
+    }
+}
+
 // The query's postings are consumed in DOC-RANGE passes: a pass takes, from every term's list,
 // the postings with doc id in [d_lo, d_hi) -- a contiguous piece of each doc-sorted list -- so
 // that all pieces together fit the LDS stage (d_hi is halved towards d_lo until they do).  A doc's
 // postings all fall into the same pass, so the owner search never leaves LDS, whatever the
 // length of the lists.
+//
+// WAND-style pruning (exact): passes visit the docs in ascending id order, so once k docs have
+// been scored every later doc has to BEAT the current k-th best score theta (a tie loses on the
+// id).  An owner posting first learns from the staged doc ids -- LDS only -- which query terms
+// hold its doc, and sums their bounds in query-term order: term_ub (already in LDS), and if that
+// still exceeds theta the tighter block_ub of the blocks its postings sit in.  Rounding is
+// monotone, so fl(sum of bounds) >= fl(sum of contributions): a doc whose bound does not exceed
+// theta is dropped before any of its term frequencies / doc length / collection id is fetched
+// -- the random 4-byte gathers that dominate long lists.  theta is refreshed at the end of a pass
+// when enough new docs have entered the buffer.
 __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
-    const double* __restrict__ idf, double avgdl, double k1, double b, int64_t n_docs,
-    int64_t id_base, const int32_t* __restrict__ query_terms, int max_terms, int k,
+    const double* __restrict__ idf, const double* __restrict__ term_ub,
+    const double* __restrict__ block_ub, double avgdl, double k1, double b, int64_t n_docs,
+    int64_t n_vocab, int64_t id_base, const int32_t* __restrict__ query_terms, int max_terms, int k,
+    int conjunctive, const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
     __shared__ TermRange tr[THR_BM25_MAX_TERMS];
-    __shared__ double t_idf[THR_BM25_MAX_TERMS];
+    __shared__ double t_idf[THR_BM25_MAX_TERMS], t_ub[THR_BM25_MAX_TERMS];
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
-    __shared__ int n_terms, remaining;
+    __shared__ int t_slot[THR_BM25_MAX_TERMS];
+    __shared__ int n_terms, remaining, last_compact;
     __shared__ int64_t range_lo, range_hi;
     __shared__ double b_s[BM_CAP];
     __shared__ int64_t b_id[BM_CAP];
@@ -83,26 +129,39 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     __shared__ int32_t st_doc[BM_STAGE];
 
     const int q = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int nt = 0, total = 0;
-        for (int t = 0; t < max_terms; ++t) {
-            int term = query_terms[(int64_t)q * max_terms + t];
-            if (term < 0) continue;
-            int64_t lo = rowptr[term], hi = rowptr[term + 1];
-            tr[nt].lo = lo;
-            tr[nt].len = (int)(hi - lo);
-            tr[nt].cur = 0;
-            t_idf[nt] = idf[term];
-            total += (int)(hi - lo);
-            ++nt;
+    const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
+    // set-up, one thread per query term: valid terms keep their query order (a ballot prefix)
+    {
+        int term = -1;
+        if (threadIdx.x < max_terms) {
+            term = query_terms[(int64_t)q * max_terms + threadIdx.x];
+            if (term >= n_vocab) term = -1;   // unknown term: no postings
         }
-        n_terms = nt;
-        remaining = total;
-        range_lo = 0;
+        const uint64_t m = __ballot(term >= 0);   // (max_terms <= 32: all in wave 0)
+        if (threadIdx.x < max_terms && term >= 0) {
+            const int slot = __popcll(m & ((1ull << threadIdx.x) - 1ull));
+            const int64_t lo = rowptr[term], hi = rowptr[term + 1];
+            tr[slot].lo = lo;
+            tr[slot].len = (int)(hi - lo);
+            tr[slot].cur = 0;
+            t_idf[slot] = idf[term];
+            t_ub[slot] = term_ub ? term_ub[term] : INFINITY;
+        }
+        if (threadIdx.x == 0) {
+            n_terms = __popcll(m);
+            range_lo = 0;
+            last_compact = 0;
+        }
     }
     BlockTopK<BM_CAP> tk;
     tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
     const int nt = n_terms;
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int t = 0; t < nt; ++t) total += tr[t].len;
+        remaining = total;
+    }
+    __syncthreads();
 
     while (remaining > 0) {
         // ---- choose [range_lo, range_hi): everything left if it fits, else a share of the doc
@@ -148,6 +207,8 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
             st_doc[i] = post_doc[tr[t].lo + tr[t].cur + (i - t_prefix[t])];
         }
         __syncthreads();
+        const bool have_theta = b_cnt >= k && th_s > -INFINITY;
+        const double theta = th_s;
 
         for (int base = 0; base < total; base += BM_THREADS) {
             const int i = base + threadIdx.x;
@@ -163,21 +224,69 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
                 for (int e = 0; e < t && owner; ++e)
                     if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
                 if (owner) {
-                    const int32_t tf0 = post_tf[tr[t].lo + tr[t].cur + off];
-                    const double dl = (double)doclen[d];
-                    score = __dadd_rn(0.0, bm25_contrib(t_idf[t], (double)tf0, dl, avgdl, k1, b));
-                    for (int e = t + 1; e < nt; ++e) {
-                        const int f = find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-                        if (f >= 0) {
-                            const int32_t tf = post_tf[tr[e].lo + tr[e].cur + f];
-                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tf, dl, avgdl, k1, b));
+                    // which later terms hold the doc, and where (position inside the staged piece;
+                    // kept in registers for the first 8 query terms -- static indexing only --
+                    // and searched again for the rest)
+                    int pos[8];
+                    uint32_t present = 1u << t;
+                    double ub = 0.0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pos[e] = -1;
+                        if (e == t) pos[e] = off;
+                        if (e > t && e < nt) pos[e] = find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                        if (pos[e] >= 0) {
+                            present |= 1u << e;
+                            ub = __dadd_rn(ub, t_ub[e]);
                         }
+                    }
+                    for (int e = 8; e < nt; ++e) {
+                        const int f = e == t ? off : (e > t ? find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) : -1);
+                        if (f >= 0) {
+                            present |= 1u << e;
+                            ub = __dadd_rn(ub, t_ub[e]);
+                        }
+                    }
+                    auto where = [&](int e) -> int64_t {   // posting index of the doc in term e (e >= 8)
+                        const int f = e == t ? off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                        return tr[e].lo + tr[e].cur + f;
+                    };
+                    if (conjunctive && __popc(present) < nt) owner = false;
+                    if (owner && have_theta && !(ub > theta)) owner = false;
+                    if (owner && have_theta && block_ub) {
+                        double ub2 = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (pos[e] >= 0)
+                                ub2 = __dadd_rn(ub2, block_ub[(tr[e].lo + tr[e].cur + pos[e]) / BM_BLOCK]);
+                        for (int e = 8; e < nt; ++e)
+                            if (present & (1u << e)) ub2 = __dadd_rn(ub2, block_ub[where(e) / BM_BLOCK]);
+                        if (!(ub2 > theta)) owner = false;
+                    }
+                    if (owner && qc != -1 && doc_coll[d] != qc) owner = false;
+                    if (owner) {
+                        const double dl = (double)doclen[d];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (pos[e] >= 0) {
+                                const int32_t tf = post_tf[tr[e].lo + tr[e].cur + pos[e]];
+                                score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tf, dl, avgdl, k1, b));
+                            }
+                        for (int e = 8; e < nt; ++e)
+                            if (present & (1u << e))
+                                score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[where(e)], dl,
+                                                                      avgdl, k1, b));
                     }
                 }
             }
             tk.push(owner, score, (int64_t)d);
         }
         __syncthreads();
+        // a fresh theta pays for the sort once enough docs have entered since the last one
+        if (b_cnt >= k && b_cnt - last_compact >= 64) {
+            tk.compact();
+            if (threadIdx.x == 0) last_compact = b_cnt;
+        }
         if (threadIdx.x == 0) {
             for (int t = 0; t < nt; ++t) tr[t].cur += tr[t].sub;
             remaining -= total;
@@ -197,20 +306,50 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
 
 using namespace thr;
 
+extern "C" size_t thr_bm25_block_count(int64_t nnz) { return nnz > 0 ? (size_t)((nnz + BM_BLOCK - 1) / BM_BLOCK) : 0; }
+
+extern "C" int thr_bm25_bounds(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
+                               const float* doclen, const double* idf, double avgdl, double k1,
+                               double b, int64_t n_vocab, int64_t nnz, double* term_ub,
+                               double* block_ub, thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !doclen || !idf || !term_ub || !block_ub,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_vocab <= 0 || nnz <= 0 || !(avgdl > 0.0), THR_ERR_INVALID);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = (int64_t)thr_bm25_block_count(nnz);
+    hipError_t e = hipMemsetAsync(term_ub, 0, sizeof(double) * n_vocab, st);
+    if (e == hipSuccess) e = hipMemsetAsync(block_ub, 0, sizeof(double) * nb, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, rowptr,
+                       post_doc, post_tf, doclen, idf, avgdl, k1, b, n_vocab, nnz,
+                       (unsigned long long*)term_ub, (unsigned long long*)block_ub);
+    hipLaunchKernelGGL(bm25_bounds_decode, dim3((unsigned)((n_vocab + 255) / 256)), dim3(256), 0, st,
+                       (unsigned long long*)term_ub, n_vocab);
+    hipLaunchKernelGGL(bm25_bounds_decode, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st,
+                       (unsigned long long*)block_ub, nb);
+    return launch_status();
+}
+
 extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
-                             const float* doclen, const double* idf, double avgdl, double k1,
-                             double b, int64_t n_docs, int64_t id_base, const int32_t* query_terms,
-                             int n_queries, int max_terms, int k, double* out_scores,
-                             int64_t* out_ids, int32_t* out_counts, thr_stream_t stream) {
+                             const float* doclen, const double* idf, const double* term_ub,
+                             const double* block_ub, double avgdl, double k1, double b,
+                             int64_t n_docs, int64_t n_vocab, int64_t id_base,
+                             const int32_t* query_terms, int n_queries, int max_terms, int k,
+                             int conjunctive, const int32_t* doc_coll, const int32_t* query_coll,
+                             double* out_scores, int64_t* out_ids, int32_t* out_counts,
+                             thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !doclen || !idf || !query_terms ||
                       !out_scores || !out_ids || !out_counts,
                   THR_ERR_INVALID);
-    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || k <= 0 || k > THR_TOPK_MAX || max_terms <= 0 ||
-                      max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
+    THR_RETURN_IF(n_docs <= 0 || n_vocab <= 0 || n_queries <= 0 || k <= 0 || k > THR_TOPK_MAX ||
+                      max_terms <= 0 || max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
                   THR_ERR_INVALID);
+    THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
     hipLaunchKernelGGL(bm25_topk_kernel, dim3(n_queries), dim3(BM_THREADS), 0, (hipStream_t)stream,
-                       rowptr, post_doc, post_tf, doclen, idf, avgdl, k1, b, n_docs, id_base, query_terms,
-                       max_terms, k, out_scores, out_ids, out_counts);
+                       rowptr, post_doc, post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,
+                       avgdl, k1, b, n_docs, n_vocab, id_base, query_terms, max_terms, k, conjunctive,
+                       doc_coll, query_coll, out_scores, out_ids, out_counts);
     return launch_status();
 }

@@ -523,11 +523,18 @@ __device__ bool query_is_void(const float* __restrict__ queries, int n_queries, 
 
 // K2: tau[q] = kk-th largest of sample_scores[q][0..n_sample)  (+inf for void queries;
 // n_sample == 0 means "no sample pass": tau = -inf, every row is a candidate)
+// With a collection filter (query_coll[q] != -1) the sample rows of other collections count as
+// -inf: tau becomes the kk-th best SAMPLED ROW OF THAT COLLECTION, so the scan lets through about
+// as many rows of the collection as it would unfiltered rows (sample entry i is row
+// (i / unit) * stride * unit + i % unit); fewer than kk such rows in the sample -> tau = -inf.
 __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ sample_scores,
                                                   int64_t sample_ld, int n_sample, int kk,
                                                   const float* __restrict__ queries, int n_queries,
                                                   int dim, float* __restrict__ tau,
-                                                  float* __restrict__ qerr) {
+                                                  float* __restrict__ qerr,
+                                                  const int32_t* __restrict__ doc_coll,
+                                                  const int32_t* __restrict__ query_coll, int unit,
+                                                  int64_t stride, int64_t n_docs) {
     __shared__ int hist[CS_BINS];
     __shared__ int aux[8];
     __shared__ int flag;
@@ -567,8 +574,18 @@ __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ samp
         return;
     }
     const float* s = sample_scores + (int64_t)q * sample_ld;
+    const int qc = (query_coll && q < n_queries) ? query_coll[q] : -1;
     // a lower bound of the kk-th sample score is as good a threshold as the score itself
-    const uint32_t key = block_coarse_select([&](int i) { return fkey(s[i]); }, n_sample, kk, hist, aux);
+    const uint32_t key = block_coarse_select(
+        [&](int i) {
+            float v = s[i];
+            if (qc != -1) {
+                const int64_t row = (int64_t)(i / unit) * stride * unit + i % unit;
+                if (row >= n_docs || doc_coll[row] != qc) v = -INFINITY;
+            }
+            return fkey(v);
+        },
+        n_sample, kk, hist, aux);
     if (threadIdx.x == 0) tau[q] = coarse_value(key);
 }
 
@@ -623,7 +640,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores,
     int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts,
     uint32_t* __restrict__ out_flags, const uint32_t* __restrict__ redo_flags, int nseg,
-    int seg_cap) {
+    int seg_cap, const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll) {
     if (redo_flags && (redo_flags[blockIdx.x] & (THR_FLAG_CERTIFIED | THR_FLAG_OVERFLOW))) return;
     extern __shared__ float4 lds_sel[];  // [dim/4] query | hist (band) / 4 wave stage tiles (rescore)
     __shared__ int aux[8];
@@ -682,11 +699,32 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         n = n_total;
     }
 
+    // Collection filter (rag2_schema.sql:404-408): a candidate of another collection is read as
+    // score -inf and skipped everywhere below (a row that passed the scan never scores -inf
+    // itself).  The floor of the certificate still bounds every row of the RIGHT collection
+    // outside the shortlist.
+    const int qc = query_coll ? query_coll[q] : -1;
+    auto load_cand = [&](int u) -> Cand {
+        Cand e = my_ptr[(int64_t)u * my_stride];
+        if (qc != -1 && doc_coll[e.doc] != qc) e.score = -INFINITY;
+        return e;
+    };
     // candidates this thread keeps in registers (loads in flight while the query is staged)
     Cand mine[SEL_REG];
 #pragma unroll
-    for (int u = 0; u < SEL_REG; ++u)
-        mine[u] = u < my_n ? my_ptr[(int64_t)u * my_stride] : Cand{-INFINITY, 0u};
+    for (int u = 0; u < SEL_REG; ++u) mine[u] = u < my_n ? load_cand(u) : Cand{-INFINITY, 0u};
+    if (qc != -1) {   // n = the candidates that pass the filter
+        __shared__ int n_pass;
+        if (threadIdx.x == 0) n_pass = 0;
+        __syncthreads();
+        int mine_ok = 0;
+#pragma unroll
+        for (int u = 0; u < SEL_REG; ++u) mine_ok += (u < my_n && mine[u].score > -INFINITY) ? 1 : 0;
+        for (int u = SEL_REG; u < my_n; ++u) mine_ok += load_cand(u).score > -INFINITY ? 1 : 0;
+        if (mine_ok) atomicAdd(&n_pass, mine_ok);
+        __syncthreads();
+        n = n_pass;
+    }
     for (int i = threadIdx.x; i < dim / 4; i += SEL_THREADS)
         lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
     for (int i = threadIdx.x; i < CAPB; i += SEL_THREADS) {
@@ -719,13 +757,15 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
 #pragma unroll
             for (int u = 0; u < SEL_REG; ++u) {
                 const uint32_t key = fkey(mine[u].score);
-                if (u < my_n) {
+                if (u < my_n && mine[u].score > -INFINITY) {
                     if (pass == 0) atomicAdd(&hist[key >> 20], 1);
                     else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
                 }
             }
             for (int u = SEL_REG; u < my_n; ++u) {
-                const uint32_t key = fkey(my_ptr[(int64_t)u * my_stride].score);
+                const float sc = load_cand(u).score;
+                if (!(sc > -INFINITY)) continue;
+                const uint32_t key = fkey(sc);
                 if (pass == 0) atomicAdd(&hist[key >> 20], 1);
                 else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
             }
@@ -747,8 +787,8 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
                     if (p < CAPB) s_id[p] = mine[u].doc;
                 }
             for (int u = SEL_REG; u < my_n; ++u) {
-                const Cand e = my_ptr[(int64_t)u * my_stride];
-                if (e.score >= band_lo) {
+                const Cand e = load_cand(u);
+                if (e.score >= band_lo) {   // (band_lo > -inf: filtered candidates never pass)
                     const int p = atomicAdd(&n_sel, 1);
                     if (p < CAPB) s_id[p] = e.doc;
                 }
@@ -768,11 +808,12 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     if (!band_done) {
         // the band does not fit the block (or the list is short): the kprime best, exactly
         if (n > kprime) {
+            // (n > kprime candidates pass the filter, so the kprime-th largest key is a real score)
             const uint32_t tkey = block_radix_select_local(
-                [&](int u) { return fkey(my_ptr[(int64_t)u * my_stride].score); }, my_n, kprime, hist, bc);
+                [&](int u) { return fkey(load_cand(u).score); }, my_n, kprime, hist, bc);
             floor32 = fkey_inv(tkey);
             for (int u = 0; u < my_n; ++u) {
-                const Cand e = my_ptr[(int64_t)u * my_stride];
+                const Cand e = load_cand(u);
                 if (fkey(e.score) > tkey) {
                     const int p = atomicAdd(&n_sel, 1);
                     s_id[p] = e.doc;
@@ -780,7 +821,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
             }
             __syncthreads();
             for (int u = 0; u < my_n; ++u) {
-                const Cand e = my_ptr[(int64_t)u * my_stride];
+                const Cand e = load_cand(u);
                 if (fkey(e.score) == tkey) {
                     const int p = atomicAdd(&n_sel, 1);
                     if (p < kprime) s_id[p] = e.doc;
@@ -790,8 +831,11 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
             if (threadIdx.x == 0 && n_sel > kprime) n_sel = kprime;
         } else {
             for (int u = 0; u < my_n; ++u) {
-                const int p = atomicAdd(&n_sel, 1);
-                s_id[p] = my_ptr[(int64_t)u * my_stride].doc;
+                const Cand e = load_cand(u);
+                if (e.score > -INFINITY) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    s_id[p] = e.doc;
+                }
             }
         }
     }
@@ -910,7 +954,8 @@ constexpr int EX_SLABS = 64;
 __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int64_t n_docs, int dim,
     const float* __restrict__ queries, int n_queries, int k, double* __restrict__ slab_s,
-    int64_t* __restrict__ slab_id, const uint32_t* __restrict__ skip_certified) {
+    int64_t* __restrict__ slab_id, const uint32_t* __restrict__ skip_certified,
+    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll) {
     extern __shared__ float lds_qv[];
     __shared__ double b_s[EX_CAP];
     __shared__ int64_t b_id[EX_CAP];
@@ -940,6 +985,7 @@ __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
         BlockTopK<EX_CAP> tk;
         tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k);
         const double qn = s_qn;
+        const int qc = query_coll ? query_coll[q] : -1;
         const int64_t per = (n_docs + EX_SLABS - 1) / EX_SLABS;
         const int64_t lo = slab * per, hi = (lo + per < n_docs) ? lo + per : n_docs;
         for (int64_t base = lo; base < hi; base += EX_THREADS) {
@@ -948,6 +994,7 @@ __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
             double sim = -INFINITY;
             if (ok) {
                 double dn = dnorm[row];
+                if (qc != -1 && doc_coll[row] != qc) dn = 0.0;   // another collection: not a row of this search
                 if (dn > 0.0) {
                     double dot = seq_dot_f64(docs + row * dim, lds_qv, dim);
                     sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
@@ -1401,8 +1448,9 @@ template <int MODE, bool PROF = false>
 static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfrag, int n_qtiles,
                             int64_t n_row_tiles, int64_t tile_stride, const float* tau, int* seg_cnt,
                             Cand* cand, float* sample, int64_t sample_ld, hipStream_t st,
-                            int* nseg_out = nullptr, unsigned long long* stamps = nullptr,
-                            int* n_blocks = nullptr) {
+                            int* nseg_out = nullptr, const int32_t* doc_coll = nullptr,
+                            const int32_t* query_coll = nullptr, int n_queries = 0,
+                            unsigned long long* stamps = nullptr, int* n_blocks = nullptr) {
     bool shared_rows = false;
     const bool stag = qreg_staggered(dim);
     // a lane's candidate segment is (row slice, row half): at most 128 slices (256 segments, the
@@ -1421,7 +1469,8 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
         if (e != hipSuccess) return (int)e;                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(QS_NW * 64), QStag<DIM>::LDS_BYTES, st,               \
                            (const f32x4*)rows16, (const f32x4*)qfrag, n_qtiles, n_row_tiles,      \
-                           tile_stride, tau, seg_cnt, cand, CAND_CAP / nseg, sample, sample_ld);  \
+                           tile_stride, tau, seg_cnt, cand, CAND_CAP / nseg, sample, sample_ld,   \
+                           doc_coll, query_coll, n_queries);                                      \
     }
     if (stag) {
         if (dim == 512) THR_QS_LAUNCH(512) else THR_QS_LAUNCH(768)
@@ -1438,7 +1487,7 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
         hipLaunchKernelGGL(kern, grid, dim3(Q_NW * 64), QScan<DIM>::LDS_BYTES, st,                \
                            (const f32x4*)rows16, (const f32x4*)qfrag, n_qtiles, n_row_tiles,      \
                            tile_stride, tau, seg_cnt, cand, CAND_CAP / nseg, sample, sample_ld,   \
-                           stamps);                                                               \
+                           doc_coll, query_coll, n_queries, stamps);                              \
     }
     switch (dim) {
         case 512: THR_Q_LAUNCH(512) break;
@@ -1498,7 +1547,8 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                           double doc_relerr, const double* dnorm, const float* inv_norm,
                           int64_t n_docs, int dim, int64_t id_base, const float* queries,
                           int n_queries, int k, int kprime, double* out_scores, int64_t* out_ids,
-                          int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st) {
+                          int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st,
+                          const int32_t* doc_coll, const int32_t* query_coll) {
     float* tau = (float*)(ws + p.off_tau);
     const bool h = p.kind == KIND_F16;
     float* qerr = h ? (float*)(ws + p.off_qerr) : nullptr;
@@ -1514,7 +1564,8 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
             return all ? launch_scan_f16q<MODE_ALL>(dim, docs16, qfrag, p.ntiles, units, stride,
                                                     nullptr, nullptr, nullptr, smp, ld, st)
                        : launch_scan_f16q<MODE_FILTER>(dim, docs16, qfrag, p.ntiles, units, stride,
-                                                       tau, cnt, cand, nullptr, 0, st, &nseg);
+                                                       tau, cnt, cand, nullptr, 0, st, &nseg, doc_coll,
+                                                       query_coll, n_queries);
         if (h)
             return all ? launch_scan_f16<MODE_ALL>(dim, p.nq, docs, inv_norm, n_docs, queries,
                                                    n_queries, p.ntiles, units, stride, nullptr,
@@ -1538,10 +1589,12 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     if (p.sampled) {
         if ((rc = scan(true, p.sample_groups, p.sample_stride, sample, p.sample_docs))) return rc;
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, sample, p.sample_docs,
-                           (int)p.sample_docs, p.ksample, queries, n_queries, dim, tau, qerr_k2);
+                           (int)p.sample_docs, p.ksample, queries, n_queries, dim, tau, qerr_k2,
+                           doc_coll, query_coll, p.unit, p.sample_stride, n_docs);
     } else {
         hipLaunchKernelGGL(kth_select, dim3(p.qpad), dim3(256), 0, st, (const float*)nullptr,
-                           (int64_t)0, 0, p.ksample, queries, n_queries, dim, tau, qerr_k2);
+                           (int64_t)0, 0, p.ksample, queries, n_queries, dim, tau, qerr_k2,
+                           doc_coll, query_coll, p.unit, (int64_t)1, n_docs);
     }
     if ((rc = launch_status())) return rc;
     if ((rc = scan(false, p.groups, 1, nullptr, 0))) return rc;
@@ -1556,14 +1609,14 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                        select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
                        tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
                        out_ids, out_counts, out_flags, (const uint32_t*)nullptr, nseg,
-                       nseg ? CAND_CAP / nseg : 0);
+                       nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll);
     if ((rc = launch_status())) return rc;
     // second chance with a 1024-row band for the queries whose band did not fit 256 rows
     hipLaunchKernelGGL(select_rescore<SEL_BIG_BAND>, dim3(n_queries), dim3(SEL_THREADS),
                        select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
                        tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
                        out_ids, out_counts, out_flags, (const uint32_t*)out_flags, nseg,
-                       nseg ? CAND_CAP / nseg : 0);
+                       nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll);
     return launch_status();
 }
 
@@ -1581,20 +1634,22 @@ static int dense_args_ok(const void* docs, const void* dnorm, const void* inv_no
 
 extern "C" int thr_dense_topk(const float* docs, const double* dnorm, const float* inv_norm,
                               int64_t n_docs, int dim, int64_t id_base, const float* queries,
-                              int n_queries, int k, int kprime, double* out_scores,
+                              int n_queries, int k, int kprime, const int32_t* doc_coll,
+                              const int32_t* query_coll, double* out_scores,
                               int64_t* out_ids, int32_t* out_counts, uint32_t* out_flags,
                               void* workspace, size_t workspace_bytes, thr_stream_t stream) {
     clear_status();
     int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
                            out_flags, workspace, n_docs, n_queries, k, kprime);
     if (rc) return rc;
+    THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
     THR_RETURN_IF(dim <= 0 || dim % CHUNK != 0 || dim / CHUNK > 4, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS, THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, kprime);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, nullptr, 0.0, dnorm, inv_norm, n_docs, dim, id_base, queries,
                           n_queries, k, kprime, out_scores, out_ids, out_counts, out_flags,
-                          (char*)workspace, (hipStream_t)stream);
+                          (char*)workspace, (hipStream_t)stream, doc_coll, query_coll);
 }
 
 extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_queries,
@@ -1642,13 +1697,15 @@ extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim
 extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, double doc_rel_err,
                                   const double* dnorm, const float* inv_norm, int64_t n_docs,
                                   int dim, int64_t id_base, const float* queries, int n_queries,
-                                  int k, int kprime, double* out_scores, int64_t* out_ids,
+                                  int k, int kprime, const int32_t* doc_coll,
+                                  const int32_t* query_coll, double* out_scores, int64_t* out_ids,
                                   int32_t* out_counts, uint32_t* out_flags, void* workspace,
                                   size_t workspace_bytes, thr_stream_t stream) {
     clear_status();
     int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
                            out_flags, workspace, n_docs, n_queries, k, kprime);
     if (rc) return rc;
+    THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
     THR_RETURN_IF(!(doc_rel_err >= 0.0) || !(doc_rel_err < 1.0), THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
@@ -1656,7 +1713,8 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
                           inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
-                          out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream);
+                          out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream,
+                          doc_coll, query_coll);
 }
 
 extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,
@@ -1728,7 +1786,7 @@ extern "C" int thr_dense_scan_stamps_f16(const uint16_t* docs16, int64_t n_docs,
     int rc = launch_scan_f16q<MODE_FILTER, true>(
         dim, reinterpret_cast<const _Float16*>(docs16), (const _Float16*)(ws + p.off_qfrag), p.ntiles,
         p.groups, 1, (const float*)(ws + p.off_tau), (int*)(ws + p.off_cnt), (Cand*)(ws + p.off_cand),
-        nullptr, 0, st, nullptr, stamps, &blocks);
+        nullptr, 0, st, nullptr, nullptr, nullptr, 0, stamps, &blocks);
     *h_n_waves = blocks * qreg_waves(dim);
     return rc;
 }
@@ -1740,6 +1798,7 @@ extern "C" size_t thr_dense_exact_workspace_bytes(int64_t n_docs, int n_queries)
 
 extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int64_t n_docs, int dim,
                                     int64_t id_base, const float* queries, int n_queries, int k,
+                                    const int32_t* doc_coll, const int32_t* query_coll,
                                     double* out_scores, int64_t* out_ids, int32_t* out_counts,
                                     uint32_t* out_flags, void* workspace, size_t workspace_bytes,
                                     thr_stream_t stream) {
@@ -1756,7 +1815,7 @@ extern "C" int thr_dense_topk_exact(const float* docs, const double* dnorm, int6
     int64_t* slab_id = (int64_t*)(slab_s + (size_t)n_queries * EX_SLABS * k);
     hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, n_queries), dim3(EX_THREADS),
                        sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, n_queries, k,
-                       slab_s, slab_id, (const uint32_t*)nullptr);
+                       slab_s, slab_id, (const uint32_t*)nullptr, doc_coll, query_coll);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,
@@ -1777,6 +1836,7 @@ extern "C" size_t thr_dense_rescue_workspace_bytes(int n_queries, int k) {
 // once per redone query.
 extern "C" int thr_dense_rescue(const float* docs, const double* dnorm, int64_t n_docs, int dim,
                                 int64_t id_base, const float* queries, int n_queries, int k,
+                                const int32_t* doc_coll, const int32_t* query_coll,
                                 double* io_scores, int64_t* io_ids, int32_t* io_counts,
                                 uint32_t* io_flags, int32_t* n_rescued, void* workspace,
                                 size_t workspace_bytes, thr_stream_t stream) {
@@ -1794,7 +1854,7 @@ extern "C" int thr_dense_rescue(const float* docs, const double* dnorm, int64_t 
     const int rows = (n_queries + 63) / 64 > 16 ? (n_queries + 63) / 64 : (n_queries < 16 ? n_queries : 16);
     hipLaunchKernelGGL(exact_slab_topk, dim3(EX_SLABS, rows), dim3(EX_THREADS),
                        sizeof(float) * dim, st, docs, dnorm, n_docs, dim, queries, n_queries, k,
-                       slab_s, slab_id, (const uint32_t*)io_flags);
+                       slab_s, slab_id, (const uint32_t*)io_flags, doc_coll, query_coll);
     int rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(merge_lists, dim3(n_queries), dim3(256), 0, st, slab_s, slab_id,

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
     int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
     float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll, int n_queries,
     unsigned long long* __restrict__ stamps = nullptr) {
     using C = QScan<DIM>;
     constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER;
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
     });
     const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
+    // collection filter of this lane's query (-1: none): checked only for rows that pass tau
+    const int my_qc = (MODE == MODE_FILTER && query_coll && q32 * 32 + c < n_queries) ? query_coll[q32 * 32 + c] : -1;
     // Retire these loads HERE, visibly to hipcc: left pending, their first use (the first MFMA
     // of the tile loop) gets an s_waitcnt vmcnt(0) on every trip, which would drain the DMA
     // of the next half tiles each time.
@@ -257,11 +260,14 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
 #pragma unroll
             for (int x = 0; x < 16; ++x) {
                 if (acc[x] >= my_tau) {  // false for NaN
+                    const uint32_t row = row0 + (uint32_t)((x & 3) + 8 * (x >> 2));
+                    // (a filtered query pays a dependent gather here, and its wait drains the DMA
+                    // queue: the price of the WHERE clause, paid by filtered queries only)
+                    if (my_qc != -1 && doc_coll[row] != my_qc) continue;
                     if (cur < seg_cap) {
                         // (inline asm: a store hipcc can see would make it wait vmcnt(0) -- DMA
                         // included -- at the loop's back edge)
-                        const uint64_t word = (uint64_t)__float_as_uint(acc[x]) |
-                                              ((uint64_t)(row0 + (uint32_t)((x & 3) + 8 * (x >> 2))) << 32);
+                        const uint64_t word = (uint64_t)__float_as_uint(acc[x]) | ((uint64_t)row << 32);
                         asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(seg + cur), "v"(word) : "memory");
                     }
                     ++cur;
@@ -323,7 +329,8 @@ __global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
     const f32x4* __restrict__ packed, const f32x4* __restrict__ qfrag, int n_qtiles,
     int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
     int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
-    float* __restrict__ sample_scores, int64_t sample_ld) {
+    float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll, int n_queries) {
     using C = QStag<DIM>;
     constexpr int KS = C::KS, HS = C::HS, PER = C::PER, NBUF = QS_NBUF;
     extern __shared__ f32x4 lds_rows[];  // 6 half-tile buffers
@@ -339,6 +346,8 @@ __global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
         bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
     });
     const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
+    // collection filter of this lane's query (-1: none): checked only for rows that pass tau
+    const int my_qc = (MODE == MODE_FILTER && query_coll && q32 * 32 + c < n_queries) ? query_coll[q32 * 32 + c] : -1;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // retire these loads visibly to hipcc (see above)
 
     const int nseg = 2 * slot.nslices;
@@ -386,9 +395,11 @@ __global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
         const uint32_t row0 = (uint32_t)((first + (i_) * step) * tile_stride * 32) + 4 * h;        \
         _Pragma("unroll") for (int x = 0; x < 16; ++x) {                                           \
             if (acc[x] >= my_tau) { /* false for NaN */                                            \
+                const uint32_t row = row0 + (uint32_t)((x & 3) + 8 * (x >> 2));                    \
+                /* a filtered query pays a dependent gather here (its wait drains the DMA queue) */ \
+                if (my_qc != -1 && doc_coll[row] != my_qc) continue;                               \
                 if (cur < seg_cap) {                                                               \
-                    const uint64_t word = (uint64_t)__float_as_uint(acc[x]) |                      \
-                                          ((uint64_t)(row0 + (uint32_t)((x & 3) + 8 * (x >> 2))) << 32); \
+                    const uint64_t word = (uint64_t)__float_as_uint(acc[x]) | ((uint64_t)row << 32); \
                     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(seg + cur), "v"(word) : "memory"); \
                 }                                                                                  \
                 ++cur;                                                                             \

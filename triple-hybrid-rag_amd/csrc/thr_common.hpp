@@ -36,6 +36,10 @@ __device__ __forceinline__ uint64_t dkey(double d) {
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
+__device__ __forceinline__ double dkey_inv(uint64_t k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
 // ---- ranked item under the total order (score desc, id asc) ----
 struct Item {
     double s;

@@ -54,6 +54,7 @@ class GpuIndex:
         self.lex = None
         self.graph = None
         self.tokens = None
+        self.doc_coll = None
         self.tokens_packed = False
         self._ws: Optional[torch.Tensor] = None
         self._ws_rescue: Optional[torch.Tensor] = None
@@ -112,8 +113,19 @@ class GpuIndex:
         self.lex = dict(rowptr=self._t(rowptr, torch.int64), post_doc=self._t(post_doc, torch.int32),
                         post_tf=self._t(post_tf, torch.int32), doclen=self._t(doclen, torch.float32),
                         idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b))
+        L = self.lex
+        # per-term / per-128-posting score bounds for the WAND-style pruning of thr_bm25_topk
+        L["bounds"] = N.bm25_bounds(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
+                                    L["avgdl"], L["k1"], L["b"])
         if self.n_docs == 0:
             self.n_docs = int(self.lex["doclen"].shape[0])
+        return self
+
+    def set_collections(self, doc_coll) -> "GpuIndex":
+        """Per-document collection id (int32 [n], any non-negative labelling): the
+        ``p_collection`` filter of the two RPCs (rag2_schema.sql:368-373, 404-408) is applied
+        on the device BEFORE the ranking -- per query, -1 = unfiltered."""
+        self.doc_coll = self._t(doc_coll, torch.int32)
         return self
 
     def set_graph(self, ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf) -> "GpuIndex":
@@ -163,12 +175,15 @@ class GpuIndex:
         return self
 
     def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
-                     rescue: bool = True, sync: bool = True):
+                     rescue: bool = True, sync: bool = True, collections=None):
         """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
         error-bound certificate cannot prove exact (massive ties / duplicates) are redone on the
         exhaustive float64 path, on the device (thr_dense_rescue: no host read-back).
-        n_rescued is an int, or with sync=False the device int32[1] it would be read from."""
+        n_rescued is an int, or with sync=False the device int32[1] it would be read from.
+        collections: int32 [nq] collection id per query (-1 = unfiltered), applied before the
+        ranking (set_collections)."""
         queries = self._t(queries, torch.float32)
+        dc, qc = self._qcoll(collections, queries.shape[0])
         if self.shortlist != "f32":
             # tau must sit clearly below the k-th score for the quantisation-aware certificate:
             # k' = 192 puts it ~6e-3 below on a 1M-row corpus, ~6x the f16 error bound
@@ -176,19 +191,20 @@ class GpuIndex:
             ws = self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim,
                                                              queries.shape[0], kp))
             S, I, cnt, flg = N.dense_topk_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
-                                              self.inv_norm, queries, k, kp, self.doc_base, ws)
+                                              self.inv_norm, queries, k, kp, self.doc_base, ws,
+                                              doc_coll=dc, query_coll=qc)
         else:
             kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
             ws = self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
             S, I, cnt, flg = N.dense_topk(self.docs, self.dnorm, self.inv_norm, queries, k, kp,
-                                          self.doc_base, ws)
+                                          self.doc_base, ws, doc_coll=dc, query_coll=qc)
         n_rescued = 0
         if rescue:
             need = N.dense_rescue_workspace_bytes(queries.shape[0], k)
             if self._ws_rescue is None or self._ws_rescue.numel() < need:
                 self._ws_rescue = torch.empty(need, dtype=torch.uint8, device=self.device)
             n_rescued = N.dense_rescue(self.docs, self.dnorm, queries, S, I, cnt, flg,
-                                       self.doc_base, self._ws_rescue)
+                                       self.doc_base, self._ws_rescue, doc_coll=dc, query_coll=qc)
             if sync:
                 n_rescued = int(n_rescued)
         return S, I, cnt, n_rescued
@@ -204,11 +220,26 @@ class GpuIndex:
         else:
             N.dense_scan_probe(self.docs, self.inv_norm, queries, self._ws)
 
-    def bm25_search(self, query_terms: torch.Tensor, k: int):
+    def _qcoll(self, collections, nq: int):
+        if collections is None:
+            return None, None
+        if self.doc_coll is None:
+            raise N.NativeError("collection filter without set_collections()")
+        qc = self._t(collections, torch.int32)
+        if qc.shape != (nq,):
+            raise N.NativeError("collections: one id per query")
+        return self.doc_coll, qc
+
+    def bm25_search(self, query_terms: torch.Tensor, k: int, collections=None,
+                    conjunctive: bool = False, prune: bool = True):
+        """collections: int32 [nq] collection id per query (-1 = unfiltered) or None."""
         L = self.lex
+        qt = self._t(query_terms, torch.int32)
+        dc, qc = self._qcoll(collections, qt.shape[0])
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
-                           L["avgdl"], self._t(query_terms, torch.int32), k, self.doc_base,
-                           L["k1"], L["b"])
+                           L["avgdl"], qt, k, self.doc_base, L["k1"], L["b"],
+                           bounds=L["bounds"] if prune else None, conjunctive=conjunctive,
+                           doc_coll=dc, query_coll=qc)
 
     def graph_search(self, query_seeds: torch.Tensor, k: int, hops: int = 2):
         G = self.graph
