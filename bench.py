@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec for the fused top-10 of the RAG 2.0 retrieval hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config dense|dense_bm25|triple|triple_rerank|all]
 
-A step = one pass of the hot path over one batch of ``--queries`` (default 1536) synthetic queries:
-dense brute-force cosine top-100 over the HBM-resident corpus -> (all-gather + merge when
-N > 1) -> weighted RRF -> fused top-10.  Workload at N = 1 is BASELINE.json configs[1]
-(1M-doc / 768-d dense-only top-10).  For N > 1 the SAME corpus is sharded by document
-across the ranks (strong scaling, one process per GPU, RCCL all-gather of the per-shard
-top-100).  Inputs are resident in HBM before the timed region.
+A step = one pass of the hot path over one batch of ``--queries`` (default 2048) synthetic
+queries, inputs resident in HBM.  The headline line is always BASELINE.json configs[1]
+(1M-doc / 768-d dense-only cosine top-100 -> RRF -> fused top-10); at N = 1 the default run also
+times configs[2]-[4]'s pipelines on the same corpus (``configs`` in the JSON): dense + BM25,
+triple-hybrid, triple-hybrid + MaxSim rerank of the fused top-100.  For N > 1 the SAME corpus is
+sharded by document across the ranks (strong scaling, one process per GPU, RCCL all-gather of
+the per-shard top-k per channel, second all-gather for the rerank scores) and only ``--config``
+(default dense) is timed.
 
 The JSON line also carries
-  roofline         the dense scan kernel of the timed path, launched alone through
-                   thr_dense_scan_probe[_f16] and timed with HIP events on its own stream:
-                   2*N*D*Q flops per launch / average launch time against the dense MFMA peak of
-                   its input type, the PMC HBM bytes per launch (`traffic`), and SURVEY 8(d)'s
-                   passes*N*D*bytes/t figure against 8 TB/s (`hbm_formula`)
-  other_shortlists the same step with the other shortlist scans (same bits out)
-  cpu_baseline     the CPU oracle's fast path (float32 BLAS shortlist + float64 rescoring,
-                   oracle/thr_oracle.py dense_topk_fast) timed on this host's cores on a bounded
-                   sample of the same workload (rank 0, N = 1 only)
+  roofline      the dominant kernel -- the dense scan -- launched alone through
+                thr_dense_scan_probe_f16 and timed with HIP events on its stream: 2*N*D*Q flops
+                per launch / average launch time against the dense f16 MFMA peak; ``traffic`` =
+                HBM bytes per launch from the committed PMC pass (profiles/, same shape; null
+                when the shape differs) and the HBM GB/s that traffic means at the measured time
+  cpu_baseline  the CPU oracle's fast path (float32 BLAS shortlist + float64 rescoring,
+                oracle/thr_oracle.py) timed on this host's cores on a bounded sample (rank 0, N = 1)
+  latency       the drop-in ``RAG2Retriever.retrieve()`` one query at a time (p50 / p95), and the
+                scan alone for batches of 1 / 32 / 256 queries as HBM GB/s (one pass over the
+                float16 copy: the regime where the HBM roofline applies)
 """
 from __future__ import annotations
 
@@ -39,6 +42,10 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0
 MFMA_F16_PEAK_TFLOPS = 2500.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+CONFIGS = ("dense", "dense_bm25", "triple", "triple_rerank")
+BASELINE_CONFIG = {"dense": "configs[1]", "dense_bm25": "configs[2]", "triple": "configs[3]",
+                   "triple_rerank": "configs[4]"}
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_scan_f16qs_counters.json")
 
 
 def parse():
@@ -52,6 +59,10 @@ def parse():
                     help="queries per step (batch): 2048 = 8 workgroup tiles of 256 queries x 4 "
                          "row slices per XCD, one full round of the 256 CUs for the default scan")
     ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--config", choices=CONFIGS + ("all",), default=None,
+                    help="pipeline to time; default: all four at N = 1 (headline = dense), dense at N > 1")
+    ap.add_argument("--token-docs", type=int, default=0,
+                    help="docs that get a late-interaction token matrix (default: all; 32 KiB each)")
     ap.add_argument("--doc-shards", type=int, default=0,
                     help="N > 1: split the corpus into this many document shards (default N: the "
                          "pure document-sharded layout); the N / doc-shards groups are replicas "
@@ -60,12 +71,37 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=2048)
     ap.add_argument("--probe-reps", type=int, default=5)
     ap.add_argument("--no-extras", "--no-f16-extra", dest="no_extras", action="store_true",
-                    help="skip the measurements of the other shortlist flavours reported next to "
-                         "the primary one")
+                    help="skip the other shortlist flavours, the other configs and the latency section")
     ap.add_argument("--shortlist", choices=("auto", "f16-inline", "f16", "f32"), default="auto",
                     help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16 copy; "
                          "results are the same float64-exact bits in every flavour (DESIGN.md 4.1)")
     return ap.parse_args()
+
+
+def event_ms(fn, reps, torch):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def device_tokens(torch, start, count, d_tokens=128, tok_dim=128, seed=1234 + 3, block=8192):
+    """Unit-norm float16 token matrices [count, d_tokens, tok_dim] for global docs
+    [start, start+count), generated ON THE DEVICE in blocks seeded by the global block index
+    (a shard holds what the unsharded store holds; 32.8 GB per 1M docs never touches the host)."""
+    out = torch.empty((count, d_tokens, tok_dim), dtype=torch.float16, device="cuda")
+    g = torch.Generator(device="cuda")
+    for b in range(start // block, (start + count - 1) // block + 1):
+        g.manual_seed(seed * 1_000_003 + b)
+        x = torch.randn((block, d_tokens, tok_dim), generator=g, device="cuda", dtype=torch.float32)
+        x = torch.nn.functional.normalize(x, dim=2).to(torch.float16)
+        lo, hi = max(start, b * block), min(start + count, (b + 1) * block)
+        out[lo - start:hi - start] = x[lo - b * block:hi - b * block]
+    return out
 
 
 def main():
@@ -74,7 +110,7 @@ def main():
     import torch.distributed as dist
     import triple_hybrid_rag_amd as T
     from triple_hybrid_rag_amd import synth
-    from triple_hybrid_rag_amd.distributed import ShardedIndex, shard_range
+    from triple_hybrid_rag_amd.distributed import ShardedIndex, layout_2d, replica_groups, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,16 +122,22 @@ def main():
     # (sharding, groups, exchange through the host, merge) on a one-GPU box; not a measurement
     rehearsal = os.environ.get("THR_BENCH_REHEARSAL") == "1"
     torch.cuda.set_device(0 if rehearsal else local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+    which = args.config or ("all" if world == 1 and not args.no_extras else "dense")
+    run_cfgs = list(CONFIGS) if which == "all" else [which]
+    need_lex = any(c != "dense" for c in run_cfgs)
+    need_graph = any(c.startswith("triple") for c in run_cfgs)
+    need_tok = "triple_rerank" in run_cfgs
 
     # ---- inputs (deterministic, identical for every world size) ----
-    from triple_hybrid_rag_amd.distributed import layout_2d, replica_groups
     doc_shards = args.doc_shards or world
     shard, replica, _ = layout_2d(rank, world, doc_shards)
     n_replicas = world // doc_shards
@@ -103,26 +145,69 @@ def main():
     if world > 1 and n_replicas > 1:
         group = replica_groups(world, doc_shards)[replica]
     lo, hi = shard_range(args.docs, shard, doc_shards)
+    n_local = hi - lo
+    nq = args.queries
     t0 = time.time()
-    docs = synth.dense_rows(lo, hi - lo, args.dim)
-    queries = synth.dense_queries(args.queries * n_replicas, args.dim, args.docs)
+    docs = synth.dense_rows(lo, n_local, args.dim)
+    queries = synth.dense_queries(nq * n_replicas, args.dim, args.docs)
     queries = np.ascontiguousarray(queries[replica::n_replicas])   # this replica's batch
-    gen_s = time.time() - t0
     index = T.GpuIndex(doc_base=lo).set_dense(docs, shortlist=args.shortlist)
-    index.reserve(args.queries, 100)   # workspaces are part of the resident index, not of a step
+    qt = seeds = qtok = None
+    csr = graph = None
+    if need_lex:
+        v = synth.vocab_size(args.docs)
+        d_, t_, f_ = synth.lexical_rows(lo, n_local, args.docs)
+        csr = synth.build_lexical_csr(d_, t_, f_, n_local, v)
+        df = torch.from_numpy(csr.df_local.copy())
+        sdl = torch.tensor([csr.sum_dl_local], dtype=torch.float64)
+        if world > 1:   # global statistics: every shard scores as the whole corpus would
+            dev_ = "cpu" if rehearsal else "cuda"
+            df, sdl = df.to(dev_), sdl.to(dev_)
+            dist.all_reduce(df)
+            dist.all_reduce(sdl)
+            df, sdl = df.cpu(), sdl.cpu()
+        df = df.numpy()
+        idf = np.log(1.0 + (args.docs - df.astype(np.float64) + 0.5) / (df.astype(np.float64) + 0.5))
+        index.set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, float(sdl.item()) / args.docs)
+        dfq = df.copy()
+        dfq[dfq > 0.01 * args.docs] = 0          # stop words are not query terms (1 % of the docs)
+        qt = synth.lexical_queries(nq * n_replicas, dfq, 4)[replica::n_replicas]
+    if need_graph:
+        graph = synth.build_graph(args.docs, lo, hi)
+        index.set_graph(graph.ent_rowptr, graph.ent_col, graph.men_rowptr, graph.men_chunk, graph.men_conf)
+        seeds = synth.graph_queries(nq * n_replicas, args.docs, 3)[replica::n_replicas]
+    if need_tok:
+        n_tok = min(n_local, args.token_docs) if args.token_docs else n_local
+        index.set_tokens(device_tokens(torch, lo, n_tok))
+        g = torch.Generator(device="cuda")
+        g.manual_seed(4321 + 3)
+        qtok = torch.nn.functional.normalize(torch.randn((nq * n_replicas, 32, 128), generator=g, device="cuda"),
+                                             dim=2).to(torch.float16)[replica::n_replicas].contiguous()
+    gen_s = time.time() - t0
+    index.reserve(nq, 100)   # workspaces are part of the resident index, not of a step
     sharded = ShardedIndex(index, group=group)
     qd = torch.from_numpy(queries).cuda()
+    qtd = torch.from_numpy(np.ascontiguousarray(qt)).cuda() if qt is not None else None
+    sd = torch.from_numpy(np.ascontiguousarray(seeds)).cuda() if seeds is not None else None
     torch.cuda.synchronize()
 
-    def step():
-        return sharded.retrieve_batch(qd, top_k=args.top_k)
+    def step_fn(cfg):
+        kw = {}
+        if cfg != "dense":
+            kw["query_terms"] = qtd
+        if cfg.startswith("triple"):
+            kw["query_seeds"] = sd
+        if cfg == "triple_rerank":
+            kw.update(qtok=qtok, rerank_top_k=100)
+        w = {"lexical": 0.7, "semantic": 0.8} if cfg == "dense_bm25" else None   # configs[2]: RRF(0.8/0.7)
+        return lambda: sharded.retrieve_batch(qd, top_k=args.top_k, weights=w, **kw)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure():
+    def measure(step):
         """W warm-up steps, then K timed steps between barriers; max over ranks."""
         res, counters = None, []
         for _ in range(args.warmup):
@@ -156,99 +241,234 @@ def main():
             index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(
                 index.docs, keep_copy=name == "f16")
 
-    def pmc(name):
-        """Counters of the scan kernel from the committed --pmc passes (profiles/): HBM-side
-        bytes per launch (FETCH_SIZE x2 on gfx950) and the MFMA pipe's busy share.  Only
-        valid for the shape they were measured on."""
+    def committed_pmc():
+        """HBM bytes per launch of the default scan from the committed --pmc pass (profiles/,
+        FETCH_SIZE x2 on gfx950): NOT measured in this run, and only quoted for the shape it
+        was collected on."""
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_dense_scan_traffic.json")) as f:
+            with open(PMC_PROFILE) as f:
                 pm = json.load(f)
-            e = pm["flavours"][name]
-            if pm["n_docs"] == n_local and pm["dim"] == args.dim and pm["queries"] == args.queries:
-                return e
+            if (pm["n_docs"], pm["dim"], pm["queries"]) == (n_local, args.dim, nq):
+                return pm
         except (OSError, KeyError, ValueError):
             pass
-        return {}
+        return None
 
-    def probe_scan(name):
+    def probe_scan(name, queries_dev=None, reps=None):
         """The streaming scan kernel alone: average launch time from HIP events on its stream."""
-        stream = torch.cuda.current_stream()
-        index.scan_probe(qd)  # warm; same workspace (and tau) as the timed searches
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record(stream)
-        for _ in range(args.probe_reps):
-            index.scan_probe(qd)
-        ev1.record(stream)
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / args.probe_reps
+        qx = qd if queries_dev is None else queries_dev
+        if queries_dev is not None:
+            index.dense_search(qx, 100, rescue=False)   # thresholds / query image for this batch
+        ms = event_ms(lambda: index.scan_probe(qx), reps or args.probe_reps, torch)
         f16 = name != "f32"
-        qt = 32 if name == "f32" else T._native.dense_f16_query_tile(args.dim, name == "f16",
-                                                                      args.queries)
-        passes = (args.queries + qt - 1) // qt
-        flops = 2.0 * n_local * args.dim * args.queries
+        n_q = qx.shape[0]
+        qtile = 32 if name == "f32" else T._native.dense_f16_query_tile(args.dim, name == "f16", n_q)
+        flops = 2.0 * n_local * args.dim * n_q
         peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
         ach = flops / (ms * 1e-3) / 1e12
-        row_bytes = args.dim * (2 if name == "f16" else 4)
-        alg = passes * n_local * row_bytes
-        hbm = alg / (ms * 1e-3) / 1e9
-        c = pmc(name)
-        return {"bound": "mfma", "kernel": f"{KERNEL[name]} ({qt} queries/pass)",
-                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": c.get("hbm_bytes_per_launch"),
-                "launch_ms": round(ms, 4), "flops_per_launch": flops,
-                "mfma_busy": c.get("mfma_busy"),
-                # SURVEY 8(d)'s dense-scan figure (passes * N * D * bytes / t against 8 TB/s).  The
-                # query tiles of a row slice now share each row through their XCD's L2, so the
-                # bytes that reach HBM are `traffic`, not this product: the figure can exceed 1.
-                "hbm_formula": {"passes": passes, "algorithmic_bytes_per_launch": alg,
-                                "achieved": round(hbm, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": round(hbm / HBM_PEAK_GBPS, 4)}}
+        out = {"bound": "mfma", "kernel": f"{KERNEL[name]} ({qtile} queries per workgroup)",
+               "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+               "frac": round(ach / peak, 4), "traffic": None,
+               "launch_ms": round(ms, 4), "flops_per_launch": flops}
+        pm = committed_pmc() if (name == "f16" and queries_dev is None) else None
+        if pm:
+            out["traffic"] = pm["hbm_read_bytes_per_launch"]
+            out["traffic_source"] = "profiles/r2_scan_f16qs_counters.json (separate rocprofv3 --pmc run, same shape)"
+            out["hbm_gbps_at_this_launch_time"] = round(pm["hbm_read_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
+            out["mfma_pipe_busy_under_pmc"] = pm.get("mfma_pipe_busy")
+            out["clock_ghz_under_pmc"] = pm.get("clock_ghz")
+        return out
 
-    n_local = hi - lo
     primary = index.shortlist
-    res, rescued, elapsed = measure()
-    qps = args.steps * args.queries * n_replicas / elapsed   # every replica serves its own batch
+    res, rescued, elapsed = measure(step_fn(run_cfgs[0] if which != "all" else "dense"))
+    head_cfg = run_cfgs[0] if which != "all" else "dense"
+    qps = args.steps * nq * n_replicas / elapsed   # every replica serves its own batch
     roofline = probe_scan(primary)
+    head_ids = res.ids.clone()
+
+    # ---- the other configs (N = 1 default run): same corpus, same batch ----
+    cfg_out = {}
+    chan = {}
+    if which == "all":
+        for cfg in CONFIGS[1:]:
+            r2, resc2, el2 = measure(step_fn(cfg))
+            cfg_out[cfg] = {"baseline_config": BASELINE_CONFIG[cfg],
+                            "value": round(args.steps * nq / el2, 1), "unit": "queries/s",
+                            "ms_per_step": round(1e3 * el2 / args.steps, 3), "rescued_queries": resc2,
+                            "_ids": r2.ids}
+        # per-stage launch times, each stage alone (HIP events)
+        Ss, Is, _, _ = index.dense_search(qd, 100, sync=False)
+        Sl, Il, _ = index.bm25_search(qtd, 50)
+        Sg, Ig, _ = index.graph_search(sd, 50, 2)
+        fused = T._native.rrf_fuse(Il, Is, Ig, 100, 0.7, 0.8, 1.0)
+        post = int(sum(int(csr.df_local[t]) for row in qt for t in row if t >= 0))
+        ms_b = event_ms(lambda: index.bm25_search(qtd, 50), 5, torch)
+        ms_g = event_ms(lambda: index.graph_search(sd, 50, 2), 5, torch)
+        ms_r = event_ms(lambda: T._native.rrf_fuse(Il, Is, Ig, 10, 0.7, 0.8, 1.0), 5, torch)
+        ms_m = event_ms(lambda: index.maxsim(qtok, fused[0]), 5, torch)
+        ms_d = event_ms(lambda: index.dense_search(qd, 100, sync=False), 5, torch)
+        by_m = nq * 100 * 128 * 128 * 2
+        chan = {"dense_search_ms": round(ms_d, 3),
+                "bm25": {"ms": round(ms_b, 3), "postings_per_query": round(post / nq, 1),
+                         "algorithmic_GBps": round((post * 12 + nq * 64) / ms_b / 1e6, 1)},
+                "graph": {"ms": round(ms_g, 3), "algorithmic_GBps": round(8800 * nq / ms_g / 1e6, 1)},
+                "rrf_ms": round(ms_r, 3),
+                "maxsim": {"ms": round(ms_m, 3), "algorithmic_GBps": round(by_m / ms_m / 1e6, 1),
+                           "frac_of_hbm_8TBps": round(by_m / ms_m / 1e6 / HBM_PEAK_GBPS, 4),
+                           "TFLOPs": round(2.0 * nq * 100 * 32 * 128 * 128 / ms_m / 1e9, 1)}}
 
     # ---- the other shortlist flavours, measured in the same run for comparison ----
     extras = {}
-    if not args.no_extras and args.dim in (512, 768, 1024):
-        ids0 = res.ids.clone()
+    if world == 1 and not args.no_extras and args.dim in (512, 768, 1024):
         for name in FLAVOURS:
             if name == primary:
                 continue
             set_flavour(name)
-            r2, resc2, el2 = measure()
-            extras[name] = {"value": round(args.steps * args.queries * n_replicas / el2, 1),
-                            "unit": "queries/s",
-                            "ms_per_step": round(1e3 * el2 / args.steps, 3),
-                            "rescued_queries": resc2, "roofline": probe_scan(name),
-                            "fused_top10_identical_to_primary": bool(torch.equal(r2.ids, ids0))}
+            r2, resc2, el2 = measure(step_fn("dense"))
+            pr = probe_scan(name)
+            extras[name] = {"value": round(args.steps * nq / el2, 1), "unit": "queries/s",
+                            "ms_per_step": round(1e3 * el2 / args.steps, 3), "rescued_queries": resc2,
+                            "scan": {k: pr[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launch_ms")},
+                            "fused_top10_identical_to_primary": bool(torch.equal(r2.ids, head_ids))}
         set_flavour(primary)
+
+    # ---- single-query regime (N = 1): drop-in retrieve() latency; the scan at small batches ----
+    latency = None
+    if world == 1 and not args.no_extras:
+        latency = {"scan_small_batches": []}
+        copy_bytes = n_local * args.dim * 2
+        for b in (1, 32, 256):
+            pr = probe_scan(primary, qd[:b].contiguous(), reps=10)
+            latency["scan_small_batches"].append({
+                "queries": b, "launch_ms": pr["launch_ms"],
+                "hbm_GBps_one_pass_over_the_f16_copy": round(copy_bytes / (pr["launch_ms"] * 1e-3) / 1e9, 1),
+                "frac_of_hbm_8TBps": round(copy_bytes / (pr["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+        index.dense_search(qd, 100, rescue=False)
+        # batch path for ONE query end to end, host vector included: embed post-processing
+        # (thr_embed_postproc: truncate 4096 -> dim, L2-normalise) + H2D + dense + RRF
+        full = np.random.default_rng(7).standard_normal((1, 4096)).astype(np.float32)
+        pinned = torch.from_numpy(full).pin_memory()
+
+        def one_query():
+            v = T._native.embed_postproc(pinned.cuda(non_blocking=True), args.dim)
+            return index.retrieve_batch(v, top_k=args.top_k)
+        for _ in range(3):
+            one_query()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(30):
+            t1 = time.perf_counter()
+            r = one_query()
+            r.ids.cpu()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        latency["batch_api_one_query_ms"] = {"p50": round(float(np.percentile(ts, 50)), 3),
+                                             "p95": round(float(np.percentile(ts, 95)), 3),
+                                             "includes": "H2D of a 4096-float vector, thr_embed_postproc, "
+                                                         "dense top-100, RRF, D2H of the 10 ids"}
+        # the reference's API: RAG2Retriever.retrieve(), one query per call, Python rows in / out
+        import asyncio
+        from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+        from triple_hybrid_rag_amd.config import SETTINGS
+        from triple_hybrid_rag_amd.rag2.retrieval import RAG2Retriever
+        SETTINGS.rag2_safety_threshold, SETTINGS.rag2_denoise_alpha = 0.0, 0.0
+        store = CorpusStore.synthetic(n_local, vocab_size=synth.vocab_size(args.docs) if need_lex else 0)
+        client = GpuIndexClient(index, store, org_id="org")
+
+        class Emb:
+            def __init__(self):
+                self.i = 0
+
+            def embed_query(self, text):
+                self.i += 1
+                return queries[self.i % nq].tolist()
+
+        retr = RAG2Retriever(org_id="org", embedder=Emb(), query_planner=object())
+        retr._supabase = client
+        text = "t100 t2000 t77" if need_lex else ""
+        ts = []
+        for i in range(33):
+            t1 = time.perf_counter()
+            out = asyncio.run(retr.retrieve(text, top_k=args.top_k, skip_planning=True, skip_rerank=True))
+            if i >= 3:
+                ts.append((time.perf_counter() - t1) * 1e3)
+        latency["dropin_retrieve_ms"] = {"p50": round(float(np.percentile(ts, 50)), 3),
+                                         "p95": round(float(np.percentile(ts, 95)), 3),
+                                         "contexts": len(out.contexts),
+                                         "channels": "lexical + semantic" if need_lex else "semantic"}
 
     # ---- exactness of what was timed + CPU baseline (rank 0, N = 1) ----
     cpu = None
     check = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle as CO
         from oracle import thr_oracle as O
         torch.set_num_threads(os.cpu_count() or 1)
-        nq_cpu = min(args.cpu_queries, args.queries)
+        nq_cpu = min(args.cpu_queries, nq)
         dn = index.dnorm.cpu().numpy()
         t0 = time.perf_counter()
         Sc, Ic = O.dense_topk_fast(docs, queries[:nq_cpu], 100, dnorm=dn)
-        fused = [O.fused_topk_ids(None, list(i), None, args.top_k)[0] for i in Ic]
+        fused_ids = [O.fused_topk_ids(None, list(i), None, args.top_k)[0] for i in Ic]
         cpu_s = time.perf_counter() - t0
         cpu = {"value": round(nq_cpu / cpu_s, 2), "unit": "queries/s", "cores": os.cpu_count(),
                "kind": "port",
-               "sample": f"{nq_cpu} of the {args.queries} queries over the full "
+               "sample": f"{nq_cpu} of the {nq} queries over the full "
                          f"{args.docs}x{args.dim} corpus (fp32 BLAS shortlist + fp64 rescoring "
                          f"+ RRF), {cpu_s:.1f} s"}
-        ids = res.ids.cpu().numpy()
-        same = sum(list(ids[i]) == fused[i] for i in range(nq_cpu))
-        check = {"fused_top10_identical": f"{same}/{nq_cpu}", "recall_at_10": round(float(np.mean(
-            [len(set(ids[i]) & set(fused[i])) / args.top_k for i in range(nq_cpu)])), 4)}
+        ids = head_ids.cpu().numpy()
+        if head_cfg == "dense":
+            same = sum(list(ids[i]) == fused_ids[i] for i in range(nq_cpu))
+            check = {"fused_top10_identical": f"{same}/{nq_cpu}", "recall_at_10": round(float(np.mean(
+                [len(set(ids[i]) & set(fused_ids[i])) / args.top_k for i in range(nq_cpu)])), 4)}
+        if which == "all":
+            # the hybrid pipelines against the oracle's channels + fusion, on a bounded sample
+            sub = list(range(0, nq, max(1, nq // 32)))[:32]
+            _, Il_o = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf,
+                                  float(sdl.item()) / args.docs, qt[sub], n_local, 50)
+            _, Ig_o = O.graph_topk(graph.ent_rowptr, graph.ent_col, graph.men_rowptr, graph.men_chunk,
+                                   graph.men_conf, seeds[sub], 2, n_local, 50)
+            block = 8192
+            for cfg in CONFIGS[1:]:
+                got = cfg_out[cfg].pop("_ids").cpu().numpy()
+                okc, checked = 0, 0
+                for j, qi in enumerate(sub):
+                    w = {"lexical": 0.7, "semantic": 0.8} if cfg == "dense_bm25" else None
+                    n_f = 100 if cfg == "triple_rerank" else args.top_k
+                    fi, _ = O.fused_topk_ids(list(Il_o[j]), list(Ic[qi]),
+                                             list(Ig_o[j]) if cfg.startswith("triple") else None, n_f, w)
+                    if cfg != "triple_rerank":
+                        okc += int(list(got[qi]) == fi)
+                        checked += 1
+                        continue
+                    if j >= 8:      # oracle MaxSim on 8 queries: their candidates' token rows are
+                        continue    # regenerated block by block on the device and copied back
+                    rows_ = {}
+                    for b in sorted({d // block for d in fi}):
+                        blk = device_tokens(torch, b * block, min(block, n_local - b * block))
+                        for d in fi:
+                            if d // block == b:
+                                rows_[d] = blk[d - b * block].cpu().numpy()
+                        del blk
+                    dt = np.stack([rows_[d] for d in fi])
+                    ms_o = CO.maxsim(qtok[qi:qi + 1].cpu().numpy(), dt, np.arange(len(fi), dtype=np.int64)[None])[0]
+                    order = O.rerank_order([float(np.float32(x)) for x in ms_o])[:args.top_k]
+                    es_ = np.array([ms_o[p_] for p_ in order])
+                    good = True
+                    for a in range(len(order)):   # identical wherever the oracle's scores are > 2e-4 apart
+                        if (a == 0 or es_[a - 1] - es_[a] > 2e-4) and (a == len(order) - 1 or es_[a] - es_[a + 1] > 2e-4):
+                            good &= int(got[qi][a]) == fi[order[a]]
+                    okc += int(good)
+                    checked += 1
+                cfg_out[cfg]["parity_sample"] = (f"{okc}/{checked} " +
+                                                 ("reranked top-10 = the oracle's MaxSim order of the oracle's fused top-100"
+                                                  if cfg == "triple_rerank" else "fused top-10 identical to the oracle"))
+    for cfg in cfg_out:
+        cfg_out[cfg].pop("_ids", None)
 
     if rank == 0:
+        names = {"dense": f"{args.docs}-doc / {args.dim}-d dense-only brute-force cosine top-{args.top_k}",
+                 "dense_bm25": f"{args.docs}-doc dense + BM25 + RRF(0.8/0.7)",
+                 "triple": f"{args.docs}-doc triple-hybrid (dense + BM25 + graph avg-deg 8)",
+                 "triple_rerank": f"{args.docs}-doc triple-hybrid + late-interaction rerank (32x128x128, top-100)"}
         out = {
             "metric": "queries/sec (fused top-10)", "value": round(qps, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -257,17 +477,22 @@ def main():
             "dtype": ("f32" if primary == "f32" else "f16") + " MFMA shortlist scan (f32 accumulate) + "
                      "f64 rescoring of the f32 rows",
             "data": "synthetic",
-            "config": {"workload": f"{args.docs}-doc / {args.dim}-d dense-only brute-force cosine "
-                                   f"top-{args.top_k} (BASELINE.json configs[1])",
-                       "docs": args.docs, "dim": args.dim, "queries_per_step": args.queries,
+            "config": {"workload": f"{names[head_cfg]} (BASELINE.json {BASELINE_CONFIG[head_cfg]})",
+                       "pipeline": head_cfg, "docs": args.docs, "dim": args.dim, "queries_per_step": nq,
                        "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": primary,
                        "parallelism": (f"doc-shard x{doc_shards}" + (f" x {n_replicas} replicas"
                                        if n_replicas > 1 else "")) if world > 1 else "single GPU",
+                       "collective_backend": backend, "world_size_seen": dist.get_world_size() if world > 1 else 1,
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if cfg_out:
+            out["configs"] = cfg_out
+            out["stages_alone"] = chan
         if extras:
             out["other_shortlists"] = extras
+        if latency:
+            out["latency"] = latency
         if check:
             out["parity_check"] = check
         print(json.dumps(out), flush=True)

@@ -35,9 +35,24 @@ def build_client(n_docs: int, dim: int, org_id: str):
     return GpuIndexClient(idx, store, org_id=org_id)
 
 
+def batch_queries(n: int, n_docs: int):
+    """Deterministic query texts over the synthetic corpus' vocabulary and entity names: three
+    terms and one entity keyword each (the lexical channel sees the terms, the graph channel the
+    entity name, the semantic channel a hash embedding of the whole text)."""
+    import numpy as np
+    from triple_hybrid_rag_amd import synth
+    r = np.random.Generator(np.random.PCG64([4321, 9]))
+    v, e = synth.vocab_size(n_docs), synth.n_entities(n_docs)
+    return [" ".join([f"t{int(t)}" for t in r.integers(0, min(v, 2000), 3)] + [f"entity{int(r.integers(0, e))}"])
+            for _ in range(n)]
+
+
 async def main() -> int:
     ap = argparse.ArgumentParser(description="RAG 2.0 Retrieval Test CLI (MI355X index)")
-    ap.add_argument("--query", "-q", required=True)
+    ap.add_argument("--query", "-q")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="(not in the reference) run this many synthetic queries -- BASELINE.json "
+                         "config 0 is 100 -- against ONE index build; --json then prints a list")
     ap.add_argument("--org-id", "-o", required=True)
     ap.add_argument("--collection", "-c")
     ap.add_argument("--top-k", "-k", type=int, default=5)
@@ -63,18 +78,30 @@ async def main() -> int:
                               embedder=HashEmbedder(model_dim=4096, store_dim=args.dim),
                               query_planner=QueryPlanner(graph=args.graph),
                               graph_enabled=args.graph)
+    if not args.query and not args.batch:
+        ap.error("--query or --batch is required")
     retriever._supabase = build_client(args.docs, args.dim, args.org_id)
+
+    def as_json(result):   # the reference's --json keys (scripts/test_rag2.py:214-235)
+        return {"success": result.success, "refused": result.refused,
+                "refusal_reason": result.refusal_reason, "max_score": result.max_rerank_score,
+                "contexts": [{"child_id": c.child_id, "document_id": c.document_id, "page": c.page,
+                              "rrf_score": c.rrf_score, "rerank_score": c.rerank_score,
+                              "text": c.text[:500], "section": c.section_heading}
+                             for c in result.contexts],
+                "timings": result.timings}
+
+    if args.batch:
+        out = []
+        for text in batch_queries(args.batch, args.docs):
+            r = await retriever.retrieve(query=text, collection=args.collection, top_k=args.top_k)
+            out.append({"query": text, **as_json(r)})
+        print(json.dumps(out))
+        return 0
     result = await retriever.retrieve(query=args.query, collection=args.collection,
                                       top_k=args.top_k)
     if args.json:
-        print(json.dumps({
-            "success": result.success, "refused": result.refused,
-            "refusal_reason": result.refusal_reason, "max_score": result.max_rerank_score,
-            "contexts": [{"child_id": c.child_id, "document_id": c.document_id, "page": c.page,
-                          "rrf_score": c.rrf_score, "rerank_score": c.rerank_score,
-                          "text": c.text[:500], "section": c.section_heading}
-                         for c in result.contexts],
-            "timings": result.timings}, indent=2))
+        print(json.dumps(as_json(result), indent=2))
     else:
         print(f"success={result.success} refused={result.refused} reason={result.refusal_reason}")
         for stage, seconds in result.timings.items():

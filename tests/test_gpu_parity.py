@@ -1030,6 +1030,66 @@ def test_dense_auto_shortlist_choice(T):
     assert T.GpuIndex().set_dense(x[:, :256].copy()).shortlist == "f32"   # no f16 kernel at dim 256
 
 
+def test_cli_config0_100_queries_match_the_oracle_pipeline(T):
+    """BASELINE.json configs[0] / SURVEY 8a11: the scripts/test_rag2.py counterpart (the
+    reference's flags and --json keys) run as a process over the 10k-doc / 768-d synthetic corpus
+    for 100 queries, every channel on; its contexts must be what the CPU oracle's channels +
+    merge + RRF + truncation give for the same texts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.rag2.embedder import HashEmbedder
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, d, top_k = 10000, 768, 5
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "test_rag2.py"), "--batch", "100",
+                          "--org-id", "org_1", "--top-k", str(top_k), "--graph", "--json", "--docs", str(n)],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("[")][-1])
+    assert len(res) == 100
+    assert set(res[0]) == {"query", "success", "refused", "refusal_reason", "max_score", "contexts", "timings"}
+    assert set(res[0]["contexts"][0]) == {"child_id", "document_id", "page", "rrf_score", "rerank_score",
+                                          "text", "section"}
+    # the oracle pipeline
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    g = synth.build_graph(n)
+    names = [f"entity{e}" for e in range(synth.n_entities(n))]
+    emb = HashEmbedder(model_dim=4096, store_dim=d)
+    for r in res:
+        text = r["query"]
+        kws = text.split()
+        terms = []
+        for kw in kws:                              # tokens of the vocabulary "t<id>", first sighting
+            if kw.startswith("t") and kw[1:].isdigit() and int(kw[1:]) < v and int(kw[1:]) not in terms:
+                terms.append(int(kw[1:]))
+        _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [terms], n, 50)
+        qv = np.array([emb.embed_query(text)], dtype=np.float32)
+        _, Id, _ = CO.dense_topk_exact(x, qv, 100)
+        per, seeds = max(1, 50 // len(kws)), []     # graph_search.py:161-170: name ILIKE %kw%, 5 keywords
+        for kw in kws[:5]:
+            hits = 0
+            for e, name in enumerate(names):
+                if kw.lower() in name:
+                    if e not in seeds:
+                        seeds.append(e)
+                    hits += 1
+                    if hits == per:
+                        break
+        seeds = seeds[:16]
+        Ig = [[]]
+        if seeds:
+            _, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf,
+                                 np.array([seeds + [-1] * (16 - len(seeds))], dtype=np.int32), 2, n, 50)
+        ei, es = O.fused_topk_ids(list(Il[0]), list(Id[0]), list(Ig[0]) if len(Ig[0]) else None, top_k)
+        assert r["success"] and not r["refused"]
+        assert [c["child_id"] for c in r["contexts"]] == [f"c{i}" for i in ei], text
+        assert [c["rrf_score"] for c in r["contexts"]] == es
+        assert {"planning", "retrieval", "fusion", "expansion", "safety"} <= set(r["timings"])
+
+
 def test_bench_multi_rank_control_flow():
     """bench.py --gpus 2 end to end on one GPU (THR_BENCH_REHEARSAL: both ranks on cuda:0, gloo in
     place of RCCL): document sharding, exchange, merge and the single JSON line of rank 0."""
@@ -1040,12 +1100,14 @@ def test_bench_multi_rank_control_flow():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, THR_BENCH_REHEARSAL="1")
     port = 29800 + os.getpid() % 1000
-    for extra, label in (([], "doc-shard x2"), (["--doc-shards", "1"], "doc-shard x1 x 2 replicas")):
+    for extra, label, cfg in (([], "doc-shard x2", []),
+                              (["--doc-shards", "1"], "doc-shard x1 x 2 replicas", []),
+                              ([], "doc-shard x2", ["--config", "triple_rerank", "--token-docs", "20000"])):
         out = subprocess.run(
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
              "--gpus", "2", "--steps", "2", "--warmup", "1", "--docs", "40000", "--queries", "192",
-             "--no-extras", "--no-cpu-baseline"] + extra,
+             "--no-extras", "--no-cpu-baseline"] + extra + cfg,
             env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1053,4 +1115,6 @@ def test_bench_multi_rank_control_flow():
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
         assert rec["config"]["parallelism"] == label and rec["config"]["rescued_queries"] == 0
+        assert rec["config"]["collective_backend"] == "gloo" and rec["config"]["world_size_seen"] == 2
+        assert rec["config"]["pipeline"] == (cfg[1] if cfg else "dense")
         port += 1
