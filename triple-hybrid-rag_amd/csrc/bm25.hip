@@ -65,6 +65,7 @@ __device__ __forceinline__ double bm25_contrib(double idf, double tf, double dl,
 // that straddles two short lists bounds both).  Kept as order-preserving uint64 keys while the
 // atomicMax passes run, decoded in place by bm25_bounds_decode.
 constexpr int BM_BLOCK = 128;
+constexpr int BM_WINDOW = 4096;    // doc slots of the mask path (16 KiB)
 
 __global__ __launch_bounds__(256) void bm25_bounds_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
@@ -92,21 +93,24 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
     }
 }
 
-// The query's postings are consumed in DOC-RANGE passes: a pass takes, from every term's list,
-// the postings with doc id in [d_lo, d_hi) -- a contiguous piece of each doc-sorted list -- so
-// that all pieces together fit the LDS stage (d_hi is halved towards d_lo until they do).  A doc's
-// postings all fall into the same pass, so the owner search never leaves LDS, whatever the
-// length of the lists.
+// The query's postings are consumed in DOC-RANGE passes.  A pass stages, from every term's list,
+// the next quota_t postings (quotas proportional to what is left of each list, together one LDS
+// stage), then takes d_hi = the smallest "last staged doc + 1" among the lists that have more
+// postings behind their quota: every posting with doc < d_hi of EVERY list is then on chip, so a
+// doc's postings all fall into the same pass and the owner search never leaves LDS, whatever
+// the length of the lists.  (No search in global memory picks the range: round 1 did that with
+// a chain of ~20 dependent loads per term and pass, the dominant cost on long lists.)  The
+// postings with doc >= d_hi stay for the next pass and are staged again.
 //
 // WAND-style pruning (exact): passes visit the docs in ascending id order, so once k docs have
 // been scored every later doc has to BEAT the current k-th best score theta (a tie loses on the
-// id).  An owner posting first learns from the staged doc ids -- LDS only -- which query terms
-// hold its doc, and sums their bounds in query-term order: term_ub (already in LDS), and if that
-// still exceeds theta the tighter block_ub of the blocks its postings sit in.  Rounding is
-// monotone, so fl(sum of bounds) >= fl(sum of contributions): a doc whose bound does not exceed
-// theta is dropped before any of its term frequencies / doc length / collection id is fetched
-// -- the random 4-byte gathers that dominate long lists.  theta is refreshed at the end of a pass
-// when enough new docs have entered the buffer.
+// id).  Phase 1 of a pass is LDS-only: an owner posting (the posting of the first query term
+// that holds its doc) learns from the staged doc ids which query terms hold the doc and sums
+// their term_ub in query-term order; rounding is monotone, so fl(sum of bounds) >= fl(sum of
+// contributions), and a doc whose bound does not exceed theta is dropped there.  The survivors
+// are compacted into an LDS list; phase 2 walks that list 512 at a time: tighter block_ub check,
+// collection filter, term-frequency / doc-length gathers, float64 score, top-k push.  theta is
+// refreshed at the end of a pass when enough new docs have entered the buffer.
 __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
@@ -115,18 +119,23 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     int64_t n_vocab, int64_t id_base, const int32_t* __restrict__ query_terms, int max_terms, int k,
     int conjunctive, const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
-    __shared__ TermRange tr[THR_BM25_MAX_TERMS];
+    __shared__ TermRange tr[THR_BM25_MAX_TERMS];   // .sub = postings of this pass, .lds_off = where staged
     __shared__ double t_idf[THR_BM25_MAX_TERMS], t_ub[THR_BM25_MAX_TERMS];
+    __shared__ int t_staged[THR_BM25_MAX_TERMS];   // postings of the term staged in this pass
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
-    __shared__ int t_slot[THR_BM25_MAX_TERMS];
-    __shared__ int n_terms, remaining, last_compact;
-    __shared__ int64_t range_lo, range_hi;
+    __shared__ int n_terms, remaining, last_compact, n_surv;
+    __shared__ int64_t d_hi, d_lo;
     __shared__ double b_s[BM_CAP];
     __shared__ int64_t b_id[BM_CAP];
     __shared__ int b_cnt;
     __shared__ double th_s;
     __shared__ int64_t th_id;
     __shared__ int32_t st_doc[BM_STAGE];
+    // mask path: mask[BM_WINDOW] (which query terms hold doc d_lo + slot) + up to BM_WINDOW surviving
+    // slots behind it; search path: up to BM_STAGE surviving staged indices.  One 24 KiB buffer.
+    __shared__ uint32_t scratch[BM_WINDOW + BM_WINDOW / 2];
+    static_assert(sizeof(uint32_t) * (BM_WINDOW + BM_WINDOW / 2) >= sizeof(uint16_t) * BM_STAGE, "survivor list must fit");
+    uint32_t* mask = scratch;
 
     const int q = blockIdx.x;
     const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
@@ -149,7 +158,6 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
         }
         if (threadIdx.x == 0) {
             n_terms = __popcll(m);
-            range_lo = 0;
             last_compact = 0;
         }
     }
@@ -164,122 +172,183 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
     __syncthreads();
 
     while (remaining > 0) {
-        // ---- choose [range_lo, range_hi): everything left if it fits, else a share of the doc
-        //      space proportional to the stage size, halved until the pieces fit ----
+        // ---- quotas: the stage is shared out in proportion to what is left of each list ----
         if (threadIdx.x == 0) {
-            int64_t span = n_docs - range_lo;
-            if (remaining > BM_STAGE) {
-                span = (int64_t)((double)span * (0.75 * BM_STAGE) / (double)remaining);
-                if (span < 1) span = 1;
+            int off = 0;
+            const int spare = BM_STAGE - 32 * nt;   // every list gets at least 32 slots
+            for (int t = 0; t < nt; ++t) {
+                const int rem = tr[t].len - tr[t].cur;
+                int quota = 32 + (int)((int64_t)spare * rem / remaining);
+                quota = quota < rem ? quota : rem;
+                tr[t].lds_off = off;
+                t_staged[t] = quota;
+                off += quota;
             }
-            range_hi = range_lo + span;
+            d_hi = INT64_MAX;
+            d_lo = INT64_MAX;
         }
         __syncthreads();
-        for (;;) {
-            if (threadIdx.x < nt) {
-                TermRange& r = tr[threadIdx.x];
-                r.sub = range_hi >= n_docs
-                            ? r.len - r.cur
-                            : count_below(post_doc + r.lo + r.cur, r.len - r.cur, range_hi);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int total = 0;
-                for (int t = 0; t < nt; ++t) {
-                    tr[t].lds_off = total;
-                    t_prefix[t] = total;
-                    total += tr[t].sub;
-                }
-                t_prefix[nt] = total;
-                // a single doc holds at most nt postings, so a one-doc range always fits
-                if (total > BM_STAGE && range_hi - range_lo > 1)
-                    range_hi = range_lo + (range_hi - range_lo) / 2;
-                else
-                    range_lo = -1 - range_lo;  // accepted (decoded below)
-            }
-            __syncthreads();
-            if (range_lo < 0) break;
+        for (int t = 0; t < nt; ++t) {
+            const int32_t* src = post_doc + tr[t].lo + tr[t].cur;
+            int32_t* dst = st_doc + tr[t].lds_off;
+            for (int i = threadIdx.x; i < t_staged[t]; i += BM_THREADS) dst[i] = src[i];
         }
+        __syncthreads();
+        if (threadIdx.x < nt) {
+            const int t = threadIdx.x;
+            if (t_staged[t] > 0 && tr[t].cur + t_staged[t] < tr[t].len)   // more postings behind the quota
+                atomicMin((unsigned long long*)&d_hi,
+                          (unsigned long long)((int64_t)st_doc[tr[t].lds_off + t_staged[t] - 1] + 1));
+            if (t_staged[t] > 0)
+                atomicMin((unsigned long long*)&d_lo, (unsigned long long)st_doc[tr[t].lds_off]);
+        }
+        __syncthreads();
+        if (threadIdx.x < nt) {
+            TermRange& r = tr[threadIdx.x];
+            r.sub = d_hi == INT64_MAX ? t_staged[threadIdx.x]
+                                      : count_below(st_doc + r.lds_off, t_staged[threadIdx.x], d_hi);
+        }
+        if (threadIdx.x == 0) n_surv = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int t = 0; t < nt; ++t) {
+                t_prefix[t] = total;
+                total += tr[t].sub;
+            }
+            t_prefix[nt] = total;
+        }
+        __syncthreads();
         const int total = t_prefix[nt];
-        for (int i = threadIdx.x; i < total; i += BM_THREADS) {
-            int t = 0;
-            while (i >= t_prefix[t + 1]) ++t;
-            st_doc[i] = post_doc[tr[t].lo + tr[t].cur + (i - t_prefix[t])];
-        }
-        __syncthreads();
         const bool have_theta = b_cnt >= k && th_s > -INFINITY;
         const double theta = th_s;
 
-        for (int base = 0; base < total; base += BM_THREADS) {
-            const int i = base + threadIdx.x;
-            bool owner = false;
-            double score = 0.0;
-            int32_t d = 0;
-            if (i < total) {
+        // ---- phase 1 (LDS only): owners, which terms hold the doc, bound against theta ----
+        // Dense lists give narrow doc ranges: when the pass's docs fit BM_WINDOW slots, every
+        // staged posting ORs its term's bit into the doc's slot -- O(1) per posting instead of a
+        // binary search per (posting, other term) -- and the slots are then the candidate docs
+        // (owner = lowest bit).  Wide ranges (sparse lists, few postings) keep the searches.
+        int64_t last = d_hi;   // one past the last doc of the pass
+        if (d_hi == INT64_MAX) {
+            last = 0;
+            for (int t = 0; t < nt; ++t)
+                if (tr[t].sub > 0) {
+                    const int64_t e = (int64_t)st_doc[tr[t].lds_off + tr[t].sub - 1] + 1;
+                    last = e > last ? e : last;
+                }
+        }
+        const int64_t first = d_lo;
+        const bool masked = total > 0 && last - first <= BM_WINDOW;
+        uint16_t* surv = masked ? reinterpret_cast<uint16_t*>(scratch + BM_WINDOW) : reinterpret_cast<uint16_t*>(scratch);
+        if (masked) {
+            const int w = (int)(last - first);
+            for (int i = threadIdx.x; i < w; i += BM_THREADS) mask[i] = 0u;
+            __syncthreads();
+            for (int i = threadIdx.x; i < total; i += BM_THREADS) {
+                int t = 0;
+                while (i >= t_prefix[t + 1]) ++t;
+                const int32_t d = st_doc[tr[t].lds_off + (i - t_prefix[t])];
+                atomicOr(&mask[d - first], 1u << t);
+            }
+            __syncthreads();
+            for (int slot = threadIdx.x; slot < w; slot += BM_THREADS) {
+                uint32_t m = mask[slot];
+                if (!m) continue;
+                if (conjunctive && __popc(m) < nt) continue;
+                if (have_theta) {
+                    double ub = 0.0;
+                    for (uint32_t r = m; r; r &= r - 1) ub = __dadd_rn(ub, t_ub[__ffs((int)r) - 1]);
+                    if (!(ub > theta)) continue;
+                }
+                surv[atomicAdd(&n_surv, 1)] = (uint16_t)slot;
+            }
+        } else {
+            for (int i = threadIdx.x; i < total; i += BM_THREADS) {
                 int t = 0;
                 while (i >= t_prefix[t + 1]) ++t;
                 const int off = i - t_prefix[t];
-                d = st_doc[i];
-                owner = true;
+                const int32_t d = st_doc[tr[t].lds_off + off];
+                bool owner = true;
                 for (int e = 0; e < t && owner; ++e)
                     if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
-                if (owner) {
-                    // which later terms hold the doc, and where (position inside the staged piece;
-                    // kept in registers for the first 8 query terms -- static indexing only --
-                    // and searched again for the rest)
-                    int pos[8];
-                    uint32_t present = 1u << t;
-                    double ub = 0.0;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        pos[e] = -1;
-                        if (e == t) pos[e] = off;
-                        if (e > t && e < nt) pos[e] = find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-                        if (pos[e] >= 0) {
-                            present |= 1u << e;
-                            ub = __dadd_rn(ub, t_ub[e]);
-                        }
+                if (!owner) continue;
+                int present = 1;
+                double ub = __dadd_rn(0.0, t_ub[t]);
+                for (int e = t + 1; e < nt; ++e)
+                    if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) {
+                        ++present;
+                        ub = __dadd_rn(ub, t_ub[e]);
                     }
-                    for (int e = 8; e < nt; ++e) {
-                        const int f = e == t ? off : (e > t ? find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) : -1);
+                if (conjunctive && present < nt) continue;
+                if (have_theta && !(ub > theta)) continue;
+                surv[atomicAdd(&n_surv, 1)] = (uint16_t)(tr[t].lds_off + off);
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: the survivors, densely ----
+        const int ns = n_surv;
+        for (int base = 0; base < ns; base += BM_THREADS) {
+            const int j = base + threadIdx.x;
+            bool keep = j < ns;
+            double score = 0.0;
+            int32_t d = 0;
+            if (keep) {
+                int t = 0, at;
+                if (masked) {   // survivor = doc slot: owner = lowest term bit, position searched
+                    d = (int32_t)(first + surv[j]);
+                    t = __ffs((int)mask[surv[j]]) - 1;
+                    at = tr[t].lds_off + find_doc(st_doc + tr[t].lds_off, tr[t].sub, d);
+                } else {        // survivor = staged index of the owner posting
+                    at = surv[j];
+                    while (t + 1 < nt && at >= tr[t + 1].lds_off) ++t;   // lds_off ascends with t
+                    d = st_doc[at];
+                }
+                // posting index of the doc in every term that holds it (first 8 terms in
+                // registers -- static indexing only --, the rest searched again when needed)
+                int64_t where[8];
+                uint32_t present = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    where[e] = -1;
+                    if (e >= t && e < nt) {
+                        const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
                         if (f >= 0) {
+                            where[e] = tr[e].lo + tr[e].cur + f;
                             present |= 1u << e;
-                            ub = __dadd_rn(ub, t_ub[e]);
                         }
                     }
-                    auto where = [&](int e) -> int64_t {   // posting index of the doc in term e (e >= 8)
-                        const int f = e == t ? off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-                        return tr[e].lo + tr[e].cur + f;
-                    };
-                    if (conjunctive && __popc(present) < nt) owner = false;
-                    if (owner && have_theta && !(ub > theta)) owner = false;
-                    if (owner && have_theta && block_ub) {
-                        double ub2 = 0.0;
+                }
+                auto where_far = [&](int e) -> int64_t {   // e >= 8
+                    const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                    return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
+                };
+                if (have_theta && block_ub) {
+                    double ub2 = 0.0;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (pos[e] >= 0)
-                                ub2 = __dadd_rn(ub2, block_ub[(tr[e].lo + tr[e].cur + pos[e]) / BM_BLOCK]);
-                        for (int e = 8; e < nt; ++e)
-                            if (present & (1u << e)) ub2 = __dadd_rn(ub2, block_ub[where(e) / BM_BLOCK]);
-                        if (!(ub2 > theta)) owner = false;
+                    for (int e = 0; e < 8; ++e)
+                        if (where[e] >= 0) ub2 = __dadd_rn(ub2, block_ub[where[e] / BM_BLOCK]);
+                    for (int e = 8 > t ? 8 : t; e < nt; ++e) {
+                        const int64_t w = where_far(e);
+                        if (w >= 0) ub2 = __dadd_rn(ub2, block_ub[w / BM_BLOCK]);
                     }
-                    if (owner && qc != -1 && doc_coll[d] != qc) owner = false;
-                    if (owner) {
-                        const double dl = (double)doclen[d];
+                    if (!(ub2 > theta)) keep = false;
+                }
+                if (keep && qc != -1 && doc_coll[d] != qc) keep = false;
+                if (keep) {
+                    const double dl = (double)doclen[d];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (pos[e] >= 0) {
-                                const int32_t tf = post_tf[tr[e].lo + tr[e].cur + pos[e]];
-                                score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tf, dl, avgdl, k1, b));
-                            }
-                        for (int e = 8; e < nt; ++e)
-                            if (present & (1u << e))
-                                score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[where(e)], dl,
-                                                                      avgdl, k1, b));
+                    for (int e = 0; e < 8; ++e)
+                        if (where[e] >= 0)
+                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[where[e]], dl, avgdl, k1, b));
+                    for (int e = 8 > t ? 8 : t; e < nt; ++e) {
+                        const int64_t w = where_far(e);
+                        if (w >= 0)
+                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[w], dl, avgdl, k1, b));
                     }
                 }
             }
-            tk.push(owner, score, (int64_t)d);
+            tk.push(keep, score, (int64_t)d);
         }
         __syncthreads();
         // a fresh theta pays for the sort once enough docs have entered since the last one
@@ -290,7 +359,6 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
         if (threadIdx.x == 0) {
             for (int t = 0; t < nt; ++t) tr[t].cur += tr[t].sub;
             remaining -= total;
-            range_lo = range_hi;  // (range_lo held the "accepted" marker)
         }
         __syncthreads();
     }

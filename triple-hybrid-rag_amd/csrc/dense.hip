@@ -660,13 +660,16 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     const double eq = qerr ? (double)qerr[q] : 0.0;
     const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
     const Cand* c = cand + (int64_t)q * CAND_CAP;
-    // A thread's candidates are my_ptr[u * my_stride], u in [0, my_n).
+    // A thread's candidates: cand_at(u), u in [0, my_n).
     //   nseg == 0  one flat list of cand_cnt[q] entries (K3b's output): thread t takes t, t+256, ..
     //   nseg  > 0  dense_scan_f16q's layout: nseg segments of seg_cap slots, segment s filled by
     //              ONE lane of the scan with cand_cnt[q * nseg + s] entries (a count above seg_cap
-    //              means entries were dropped); 256 / nseg threads share a segment.
+    //              means entries were dropped).  nseg <= 256: 256 / nseg threads share a segment;
+    //              nseg <= 512: a thread takes segments t and t + 256 (its first my_n0 items come
+    //              from the first).
     const Cand* my_ptr;
-    int my_stride, my_n;
+    const Cand* my_ptr1 = nullptr;
+    int my_stride, my_n, my_n0;
     bool overflow;
     int n;
     if (nseg == 0) {
@@ -680,16 +683,20 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         n = cnt < CAND_CAP ? cnt : CAND_CAP;
         my_ptr = c + threadIdx.x;
         my_stride = SEL_THREADS;
-        my_n = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
+        my_n = my_n0 = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
     } else {
-        const int tps = SEL_THREADS / nseg;   // host keeps nseg <= SEL_THREADS
+        const int tps = nseg <= SEL_THREADS ? SEL_THREADS / nseg : 1;   // host keeps nseg <= 2 * SEL_THREADS
         const int sg = threadIdx.x / tps, r = threadIdx.x % tps;
         int sc = sg < nseg ? cand_cnt[(int64_t)q * nseg + sg] : 0;
-        const bool over = sc > seg_cap;
+        int sc1 = sg + SEL_THREADS < nseg ? cand_cnt[(int64_t)q * nseg + sg + SEL_THREADS] : 0;
+        const bool over = sc > seg_cap || sc1 > seg_cap;
         sc = sc < seg_cap ? sc : seg_cap;
+        sc1 = sc1 < seg_cap ? sc1 : seg_cap;
         my_ptr = c + (int64_t)sg * seg_cap + r;
+        my_ptr1 = c + (int64_t)(sg + SEL_THREADS) * seg_cap;
         my_stride = tps;
-        my_n = sc > r ? (sc - r + tps - 1) / tps : 0;
+        my_n0 = sc > r ? (sc - r + tps - 1) / tps : 0;
+        my_n = my_n0 + sc1;   // (sc1 > 0 only when tps == 1)
         overflow = __syncthreads_or(over) != 0;
         __shared__ int n_total;
         if (threadIdx.x == 0) n_total = 0;
@@ -698,6 +705,9 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         __syncthreads();
         n = n_total;
     }
+    auto cand_at = [&](int u) -> Cand {
+        return u < my_n0 ? my_ptr[(int64_t)u * my_stride] : my_ptr1[u - my_n0];
+    };
 
     // Collection filter (rag2_schema.sql:404-408): a candidate of another collection is read as
     // score -inf and skipped everywhere below (a row that passed the scan never scores -inf
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     // outside the shortlist.
     const int qc = query_coll ? query_coll[q] : -1;
     auto load_cand = [&](int u) -> Cand {
-        Cand e = my_ptr[(int64_t)u * my_stride];
+        Cand e = cand_at(u);
         if (qc != -1 && doc_coll[e.doc] != qc) e.score = -INFINITY;
         return e;
     };
@@ -1200,7 +1210,7 @@ static bool qreg_staggered(int dim) {
     return !forced_q && dim <= 768;
 }
 static int qreg_waves(int dim) { return qreg_staggered(dim) ? 8 : 4; }   // 32 queries per wave
-constexpr int QREG_MAX_SEG = 256;
+constexpr int QREG_MAX_SEG = 512;
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
                            int dim = 0, bool packed = false) {
@@ -1453,9 +1463,10 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
                             unsigned long long* stamps = nullptr, int* n_blocks = nullptr) {
     bool shared_rows = false;
     const bool stag = qreg_staggered(dim);
-    // a lane's candidate segment is (row slice, row half): at most 128 slices (256 segments, the
-    // threads of select_rescore)
-    const dim3 grid = scan_grid(n_qtiles, n_row_tiles, 1, &shared_rows, (!stag && dim <= 768) ? 2 : 1, 16);
+    // a lane's candidate segment is (row slice, row half): at most 256 slices (512 segments, two
+    // per thread of select_rescore) -- enough for one block per CU when the batch is a single
+    // workgroup tile of queries
+    const dim3 grid = scan_grid(n_qtiles, n_row_tiles, 1, &shared_rows, (!stag && dim <= 768) ? 2 : 1, 32);
     const int nseg = 2 * (int)(grid.x / n_qtiles);
     if (nseg_out) *nseg_out = nseg;
     if (n_blocks) *n_blocks = (int)grid.x;
