@@ -262,7 +262,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
                 }
                 surv[atomicAdd(&n_surv, 1)] = (uint16_t)slot;
             }
-        } else {
+        } else if (have_theta) {
             for (int i = threadIdx.x; i < total; i += BM_THREADS) {
                 int t = 0;
                 while (i >= t_prefix[t + 1]) ++t;
@@ -280,8 +280,61 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
                         ub = __dadd_rn(ub, t_ub[e]);
                     }
                 if (conjunctive && present < nt) continue;
-                if (have_theta && !(ub > theta)) continue;
+                if (!(ub > theta)) continue;
                 surv[atomicAdd(&n_surv, 1)] = (uint16_t)(tr[t].lds_off + off);
+            }
+        } else {
+            // no theta yet (the first pass of a query -- the only pass of a short one): nothing
+            // can be dropped, so every owner is scored in the same sweep that finds it
+            for (int base = 0; base < total; base += BM_THREADS) {
+                const int i = base + threadIdx.x;
+                bool owner = false;
+                double score = 0.0;
+                int32_t d = 0;
+                if (i < total) {
+                    int t = 0;
+                    while (i >= t_prefix[t + 1]) ++t;
+                    const int off = i - t_prefix[t];
+                    d = st_doc[tr[t].lds_off + off];
+                    owner = true;
+                    for (int e = 0; e < t && owner; ++e)
+                        if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
+                    if (owner) {
+                        int present = 0;
+                        int64_t where[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            where[e] = -1;
+                            if (e >= t && e < nt) {
+                                const int f = e == t ? off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                                if (f >= 0) {
+                                    where[e] = tr[e].lo + tr[e].cur + f;
+                                    ++present;
+                                }
+                            }
+                        }
+                        auto far = [&](int e) -> int64_t {   // terms beyond the 8th: searched when needed
+                            const int f = e < t ? -1 : (e == t ? off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d));
+                            return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
+                        };
+                        for (int e = 8; e < nt; ++e) present += far(e) >= 0 ? 1 : 0;
+                        if (conjunctive && present < nt) owner = false;
+                        if (owner && qc != -1 && doc_coll[d] != qc) owner = false;
+                        if (owner) {
+                            const double dl = (double)doclen[d];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (where[e] >= 0)
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[where[e]], dl, avgdl, k1, b));
+                            for (int e = 8; e < nt; ++e) {
+                                const int64_t w = far(e);
+                                if (w >= 0)
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[w], dl, avgdl, k1, b));
+                            }
+                        }
+                    }
+                }
+                tk.push(owner, score, (int64_t)d);
             }
         }
         __syncthreads();
