@@ -4,6 +4,7 @@ Bars (BASELINE.json north_star): ids / rank order bit-exact; cosine and BM25
 scores within 1e-5 (the float64 rescoring in fact reproduces the oracle's bits,
 which is what is asserted); MaxSim within 1e-4 absolute (fp32 MFMA accumulate).
 """
+import os
 import numpy as np
 import pytest
 
@@ -765,7 +766,12 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
         # holds the NORMALISED rows, NaN for rows without an embedding and for the tile padding
         img = idx.docs16.cpu().numpy()
         tiles = img.shape[0] // 32
-        rows = img.reshape(tiles, d // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(tiles * 32, d)
+        if os.environ.get("THR_DENSE_MFMA") != "32" and d in (512, 768):
+            # [tile][k32][row half ra][dim group g][r16][8]: the 16x16x32 MFMA's A fragments
+            rows = (img.reshape(tiles, d // 32, 2, 4, 16, 8).transpose(0, 2, 4, 1, 3, 5)
+                    .reshape(tiles * 32, d))
+        else:
+            rows = img.reshape(tiles, d // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(tiles * 32, d)
         unit = x.astype(np.float64) / np.maximum(np.linalg.norm(x.astype(np.float64), axis=1), 1e-300)[:, None]
         exp16 = unit.astype(np.float32).astype(np.float16)
         assert np.isnan(rows[n:]).all() and np.isnan(rows[:n][~nz]).all()

@@ -665,11 +665,11 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     //   nseg  > 0  dense_scan_f16q's layout: nseg segments of seg_cap slots, segment s filled by
     //              ONE lane of the scan with cand_cnt[q * nseg + s] entries (a count above seg_cap
     //              means entries were dropped).  nseg <= 256: 256 / nseg threads share a segment;
-    //              nseg <= 512: a thread takes segments t and t + 256 (its first my_n0 items come
-    //              from the first).
+    //              nseg <= 1024: a thread takes segments t, t + 256, t + 512, t + 768 (its first
+    //              my_n0 items come from the first, the next my_nx[0] from the second, ...).
     const Cand* my_ptr;
     const Cand* my_ptr1 = nullptr;
-    int my_stride, my_n, my_n0;
+    int my_stride, my_n, my_n0, my_nx[3] = {0, 0, 0};
     bool overflow;
     int n;
     if (nseg == 0) {
@@ -685,18 +685,24 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         my_stride = SEL_THREADS;
         my_n = my_n0 = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
     } else {
-        const int tps = nseg <= SEL_THREADS ? SEL_THREADS / nseg : 1;   // host keeps nseg <= 2 * SEL_THREADS
+        const int tps = nseg <= SEL_THREADS ? SEL_THREADS / nseg : 1;   // host keeps nseg <= 4 * SEL_THREADS
         const int sg = threadIdx.x / tps, r = threadIdx.x % tps;
         int sc = sg < nseg ? cand_cnt[(int64_t)q * nseg + sg] : 0;
-        int sc1 = sg + SEL_THREADS < nseg ? cand_cnt[(int64_t)q * nseg + sg + SEL_THREADS] : 0;
-        const bool over = sc > seg_cap || sc1 > seg_cap;
+        bool over = sc > seg_cap;
         sc = sc < seg_cap ? sc : seg_cap;
-        sc1 = sc1 < seg_cap ? sc1 : seg_cap;
         my_ptr = c + (int64_t)sg * seg_cap + r;
-        my_ptr1 = c + (int64_t)(sg + SEL_THREADS) * seg_cap;
         my_stride = tps;
         my_n0 = sc > r ? (sc - r + tps - 1) / tps : 0;
-        my_n = my_n0 + sc1;   // (sc1 > 0 only when tps == 1)
+        my_n = my_n0;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {   // (extra segments only when tps == 1)
+            int s2 = sg + (x + 1) * SEL_THREADS < nseg ? cand_cnt[(int64_t)q * nseg + sg + (x + 1) * SEL_THREADS] : 0;
+            over |= s2 > seg_cap;
+            s2 = s2 < seg_cap ? s2 : seg_cap;
+            my_nx[x] = s2;
+            my_n += s2;
+        }
+        my_ptr1 = c + (int64_t)(sg + SEL_THREADS) * seg_cap;
         overflow = __syncthreads_or(over) != 0;
         __shared__ int n_total;
         if (threadIdx.x == 0) n_total = 0;
@@ -706,7 +712,18 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         n = n_total;
     }
     auto cand_at = [&](int u) -> Cand {
-        return u < my_n0 ? my_ptr[(int64_t)u * my_stride] : my_ptr1[u - my_n0];
+        if (u < my_n0) return my_ptr[(int64_t)u * my_stride];
+        u -= my_n0;
+        const Cand* p = my_ptr1;
+        if (u >= my_nx[0]) {
+            u -= my_nx[0];
+            p += (int64_t)SEL_THREADS * seg_cap;
+            if (u >= my_nx[1]) {
+                u -= my_nx[1];
+                p += (int64_t)SEL_THREADS * seg_cap;
+            }
+        }
+        return p[u];
     };
 
     // Collection filter (rag2_schema.sql:404-408): a candidate of another collection is read as
@@ -1210,7 +1227,18 @@ static bool qreg_staggered(int dim) {
     return !forced_q && dim <= 768;
 }
 static int qreg_waves(int dim) { return qreg_staggered(dim) ? 8 : 4; }   // 32 queries per wave
-constexpr int QREG_MAX_SEG = 512;
+// MFMA shape of the staggered scan and therefore of the copy / query images: 16 (16x16x32, the
+// default: 2.50 ms against 2.67 ms per 2048 x 1M x 768 launch) or 32 (32x32x16,
+// THR_DENSE_MFMA=32).  Read once: the copy's layout depends on it.
+static int qreg_shape(int dim) {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("THR_DENSE_MFMA");
+        v = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return qreg_staggered(dim) ? v : 32;
+}
+constexpr int QREG_MAX_SEG = 1024;
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
                            int dim = 0, bool packed = false) {
@@ -1467,13 +1495,14 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
     // per thread of select_rescore) -- enough for one block per CU when the batch is a single
     // workgroup tile of queries
     const dim3 grid = scan_grid(n_qtiles, n_row_tiles, 1, &shared_rows, (!stag && dim <= 768) ? 2 : 1, 32);
-    const int nseg = 2 * (int)(grid.x / n_qtiles);
+    const int shape = qreg_shape(dim);
+    const int nseg = (shape == 16 ? 4 : 2) * (int)(grid.x / n_qtiles);
     if (nseg_out) *nseg_out = nseg;
     if (n_blocks) *n_blocks = (int)grid.x;
     if (PROF && !stamps) return THR_OK;   // size query
-#define THR_QS_LAUNCH(DIM)                                                                        \
+#define THR_QS_LAUNCH(DIM, SHAPE)                                                                 \
     {                                                                                             \
-        auto kern = dense_scan_f16qs<DIM, MODE>;                                                  \
+        auto kern = dense_scan_f16qs<DIM, MODE, SHAPE>;                                           \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                            QStag<DIM>::LDS_BYTES);                                \
@@ -1484,7 +1513,10 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
                            doc_coll, query_coll, n_queries);                                      \
     }
     if (stag) {
-        if (dim == 512) THR_QS_LAUNCH(512) else THR_QS_LAUNCH(768)
+        if (dim == 512 && shape == 32) THR_QS_LAUNCH(512, 32)
+        else if (dim == 512) THR_QS_LAUNCH(512, 16)
+        else if (shape == 32) THR_QS_LAUNCH(768, 32)
+        else THR_QS_LAUNCH(768, 16)
         return launch_status();
     }
 #undef THR_QS_LAUNCH
@@ -1513,12 +1545,16 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
 static int launch_pack_queries(int dim, const float* queries, int n_queries, int qpad,
                                _Float16* qfrag, float* qerr, hipStream_t st) {
     const dim3 grid((unsigned)(qpad / 32));
+    const bool s16 = qreg_shape(dim) == 16;
+#define THR_PACK(DIM, SHAPE) \
+    hipLaunchKernelGGL((pack_queries_f16<DIM, SHAPE>), grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr)
     switch (dim) {
-        case 512: hipLaunchKernelGGL(pack_queries_f16<512>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
-        case 768: hipLaunchKernelGGL(pack_queries_f16<768>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
-        case 1024: hipLaunchKernelGGL(pack_queries_f16<1024>, grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr); break;
+        case 512: if (s16) THR_PACK(512, 16); else THR_PACK(512, 32); break;
+        case 768: if (s16) THR_PACK(768, 16); else THR_PACK(768, 32); break;
+        case 1024: THR_PACK(1024, 32); break;
         default: return THR_ERR_UNSUPPORTED;
     }
+#undef THR_PACK
     return launch_status();
 }
 
@@ -1695,7 +1731,7 @@ extern "C" int thr_dense_quantize_f16(const float* docs, int64_t n_docs, int dim
         THR_RETURN_IF(dim % 16 != 0, THR_ERR_UNSUPPORTED);
         const int64_t n_pad = (n_docs + 31) / 32 * 32;
         hipLaunchKernelGGL(quantize_f16_norm, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, st,
-                           docs, n_docs, dim, reinterpret_cast<_Float16*>(docs16),
+                           docs, n_docs, dim, qreg_shape(dim), reinterpret_cast<_Float16*>(docs16),
                            reinterpret_cast<unsigned int*>(max_rel_err));
         return launch_status();
     }
