@@ -156,7 +156,8 @@ def test_dense_candidate_list_overflow_goes_to_rescue(T, shortlist):
     flags = flg.cpu().numpy()
     assert np.all(flags[:60] & T._native.THR_FLAG_OVERFLOW), "cluster queries overflow CAND_CAP"
     assert np.all((flags[:60] & 1) == 0)
-    assert np.any(flags[60:] & T._native.THR_FLAG_OVERFLOW), "their tile's list overflowed too"
+    if shortlist != "f16":   # (the default scan keeps one list per query: nothing shared to overflow)
+        assert np.any(flags[60:] & T._native.THR_FLAG_OVERFLOW), "their tile's list overflowed too"
     assert np.all((flags[60:][(flags[60:] & T._native.THR_FLAG_OVERFLOW) != 0] & 1) == 0)
     idx._ws.fill_(0xFF)
     S, I, cnt, nres = idx.dense_search(qd, 100)

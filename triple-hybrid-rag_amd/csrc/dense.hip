@@ -1263,7 +1263,13 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     p.ksample = kprime < 64 ? kprime : 64;
     // (the sample must grow with the corpus: a capped sample lets n / S * ks rows through, which
     // overflows the candidate lists of every query on a 10M-row shard)
-    int64_t target = n_docs * (int64_t)p.ksample / 4096;
+    // The sample pass costs ~ n * ks / aim, the scan's emit + K4's candidate read ~ aim: at 1M rows
+    // the two meet at aim = 4096 (profiles/r2_scan_tau_experiment.json), so aim follows sqrt(n)
+    // below that; never under 8 k' (k' = 128: 1024 = k' + 7 sigma of the passing count at ks = 64).
+    double aim = 4096.0 * sqrt((double)n_docs / 1.0e6);
+    const double aim_lo = 8.0 * kprime < 4096.0 ? 8.0 * kprime : 4096.0;
+    aim = aim < aim_lo ? aim_lo : aim > 4096.0 ? 4096.0 : aim;
+    int64_t target = (int64_t)((double)n_docs * (double)p.ksample / aim);
     if (target > SAMPLE_MAX) target = SAMPLE_MAX;
     if (target < 4 * (int64_t)p.ksample) target = 4 * (int64_t)p.ksample;
     int64_t sg = (target + p.unit - 1) / p.unit;
@@ -1487,7 +1493,7 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
                             int64_t n_row_tiles, int64_t tile_stride, const float* tau, int* seg_cnt,
                             Cand* cand, float* sample, int64_t sample_ld, hipStream_t st,
                             int* nseg_out = nullptr, const int32_t* doc_coll = nullptr,
-                            const int32_t* query_coll = nullptr, int n_queries = 0,
+                            const int32_t* query_coll = nullptr, int n_queries = 1 << 30,
                             unsigned long long* stamps = nullptr, int* n_blocks = nullptr) {
     bool shared_rows = false;
     const bool stag = qreg_staggered(dim);
@@ -1547,7 +1553,7 @@ static int launch_pack_queries(int dim, const float* queries, int n_queries, int
     const dim3 grid((unsigned)(qpad / 32));
     const bool s16 = qreg_shape(dim) == 16;
 #define THR_PACK(DIM, SHAPE) \
-    hipLaunchKernelGGL((pack_queries_f16<DIM, SHAPE>), grid, dim3(64), 0, st, queries, n_queries, (f32x4*)qfrag, qerr)
+    hipLaunchKernelGGL((pack_queries_f16<DIM, SHAPE>), grid, dim3(256), 0, st, queries, n_queries, (f32x4*)qfrag, qerr)
     switch (dim) {
         case 512: if (s16) THR_PACK(512, 16); else THR_PACK(512, 32); break;
         case 768: if (s16) THR_PACK(768, 16); else THR_PACK(768, 32); break;
@@ -1609,7 +1615,8 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     auto scan = [&](bool all, int64_t units, int64_t stride, float* smp, int64_t ld) -> int {
         if (p.qreg)
             return all ? launch_scan_f16q<MODE_ALL>(dim, docs16, qfrag, p.ntiles, units, stride,
-                                                    nullptr, nullptr, nullptr, smp, ld, st)
+                                                    nullptr, nullptr, nullptr, smp, ld, st, nullptr,
+                                                    nullptr, nullptr, n_queries)
                        : launch_scan_f16q<MODE_FILTER>(dim, docs16, qfrag, p.ntiles, units, stride,
                                                        tau, cnt, cand, nullptr, 0, st, &nseg, doc_coll,
                                                        query_coll, n_queries);
@@ -1805,7 +1812,8 @@ extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs1
         return launch_scan_f16q<MODE_FILTER>(dim, reinterpret_cast<const _Float16*>(docs16),
                                              (const _Float16*)(ws + p.off_qfrag), p.ntiles, p.groups,
                                              1, (const float*)(ws + p.off_tau), (int*)(ws + p.off_cnt),
-                                             (Cand*)(ws + p.off_cand), nullptr, 0, st);
+                                             (Cand*)(ws + p.off_cand), nullptr, 0, st, nullptr,
+                                             nullptr, nullptr, n_queries);
     }
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
@@ -1833,7 +1841,7 @@ extern "C" int thr_dense_scan_stamps_f16(const uint16_t* docs16, int64_t n_docs,
     int rc = launch_scan_f16q<MODE_FILTER, true>(
         dim, reinterpret_cast<const _Float16*>(docs16), (const _Float16*)(ws + p.off_qfrag), p.ntiles,
         p.groups, 1, (const float*)(ws + p.off_tau), (int*)(ws + p.off_cnt), (Cand*)(ws + p.off_cand),
-        nullptr, 0, st, nullptr, nullptr, nullptr, 0, stamps, &blocks);
+        nullptr, 0, st, nullptr, nullptr, nullptr, n_queries, stamps, &blocks);
     *h_n_waves = blocks * qreg_waves(dim);
     return rc;
 }

@@ -61,17 +61,19 @@ struct QScan {
 // qerr[q] = ||fp16(q) - q|| / ||q|| rounded up (the query-side term of the f16 certificate).
 // One wave per 32 queries.
 template <int DIM, int SHAPE>
-__global__ __launch_bounds__(64) void pack_queries_f16(const float* __restrict__ queries,
-                                                       int n_queries, f32x4* __restrict__ qfrag,
-                                                       float* __restrict__ qerr) {
+__global__ __launch_bounds__(256) void pack_queries_f16(const float* __restrict__ queries,
+                                                        int n_queries, f32x4* __restrict__ qfrag,
+                                                        float* __restrict__ qerr) {
     constexpr int KS = DIM / 16;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double red[4][4][32];   // [wave][e, n of query half 0 | e, n of half 1][c]
     double e = 0.0, nn = 0.0, e_hi = 0.0, n_hi = 0.0;
     // SHAPE 32: lane (c, h) of fragment s holds dims 16 s + 8 h .. + 8 of query 32 tile + c.
     // SHAPE 16: fragment qb * KS/2 + k32, lane (c, g) holds dims 32 k32 + 8 g .. + 8 of query
     //           32 tile + 16 qb + c (the B operand of v_mfma_f32_16x16x32_f16).
+    // The 4 waves of the block take every fourth fragment.
 #pragma unroll 4
-    for (int s = 0; s < KS; ++s) {
+    for (int s = wave; s < KS; s += 4) {
         int q, d0;
         if constexpr (SHAPE == 32) {
             q = blockIdx.x * 32 + (lane & 31);
@@ -105,13 +107,13 @@ __global__ __launch_bounds__(64) void pack_queries_f16(const float* __restrict__
             n_hi += n1;
         }
     }
+    // eq = ||fp16(q) - q|| / ||q||, rounded up: lanes of one query first, then the 4 waves
     if constexpr (SHAPE == 32) {
         e += __shfl_xor(e, 32, WAVE);
         nn += __shfl_xor(nn, 32, WAVE);
-        const int q = blockIdx.x * 32 + (lane & 31);
         if (lane < 32) {
-            float rel = nn > 0.0 ? (float)sqrt(e / nn) : 0.f;
-            qerr[q] = __uint_as_float(__float_as_uint(rel) + 1u);
+            red[wave][0][lane] = e;
+            red[wave][1][lane] = nn;
         }
     } else {
 #pragma unroll
@@ -122,11 +124,22 @@ __global__ __launch_bounds__(64) void pack_queries_f16(const float* __restrict__
             n_hi += __shfl_xor(n_hi, m, WAVE);
         }
         if (lane < 16) {
-            float rel = nn > 0.0 ? (float)sqrt(e / nn) : 0.f;
-            qerr[blockIdx.x * 32 + lane] = __uint_as_float(__float_as_uint(rel) + 1u);
-            rel = n_hi > 0.0 ? (float)sqrt(e_hi / n_hi) : 0.f;
-            qerr[blockIdx.x * 32 + 16 + lane] = __uint_as_float(__float_as_uint(rel) + 1u);
+            red[wave][0][lane] = e;
+            red[wave][1][lane] = nn;
+            red[wave][0][16 + lane] = e_hi;
+            red[wave][1][16 + lane] = n_hi;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double es = 0.0, ns = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            es += red[w][0][threadIdx.x];
+            ns += red[w][1][threadIdx.x];
+        }
+        const float rel = ns > 0.0 ? (float)sqrt(es / ns) : 0.f;
+        qerr[blockIdx.x * 32 + threadIdx.x] = __uint_as_float(__float_as_uint(rel) + 1u);
     }
 }
 
@@ -187,9 +200,10 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
 
     // B operands: the wave's 32 queries, all k-steps, in registers for the whole launch
     f32x4 bq[KS];
-    static_for<0, KS>([&](auto s) {
-        bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
-    });
+    if ((int64_t)q32 * 32 < n_queries)
+        static_for<0, KS>([&](auto s) {
+            bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+        });
     const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
     // collection filter of this lane's query (-1: none): checked only for rows that pass tau
     const int my_qc = (MODE == MODE_FILTER && query_coll && q32 * 32 + c < n_queries) ? query_coll[q32 * 32 + c] : -1;
@@ -486,9 +500,10 @@ __global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
     // B operands: the wave's 32 queries, every k-step, in registers for the whole launch
     // (both shapes: KS fragments of 1 KiB, image [q32 tile][KS][64 lanes])
     f32x4 bq[KS];
-    static_for<0, KS>([&](auto s) {
-        bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
-    });
+    if ((int64_t)q32 * 32 < n_queries)
+        static_for<0, KS>([&](auto s) {
+            bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+        });
     const int nseg = A::SEGS * slot.nslices;
     const int my_seg = A::SEGS * slot.slice + A::seg(lane);
     QEmit<SHAPE> em;
@@ -570,7 +585,33 @@ __global__ __launch_bounds__(QS_NW * 64) void dense_scan_f16qs(
     }
     A acc;
     f32x4 a[Q_RING];
-    if (wave < 4) {
+    if ((int64_t)q32 * 32 >= n_queries) {
+        // ---- a wave whose 32 queries are all padding (small batches: one query keeps 7 of the 8
+        // waves here): it only moves its share of the row pieces -- same barriers, same DMA order
+        // and wait counts as a working wave, no LDS reads, no MFMAs, nothing to emit.  A launch
+        // with one live wave per CU is bound by the row stream alone. ----
+        int buf = wave < 4 ? 4 : 5;   // buffer of the next half this wave issues
+        int64_t j = wave < 4 ? 4 : 5;
+        if (wave >= 4) {
+            QS_SYNC()  // barrier 0
+            if (n_half > 0) {
+                const f32x4* src = piece_src(4);
+#pragma unroll
+                for (int p = 0; p < PER; ++p) dma(src, 4, p);
+            }
+        }
+#pragma unroll 1
+        for (int64_t k = 0; k < n_half; ++k, ++j) {
+            QS_SYNC()   // A: barrier k, then half k + 4;  B: barrier k + 1, then half k + 5
+            const f32x4* src = piece_src(j);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, buf, p);
+            buf = buf + 1 == NBUF ? 0 : buf + 1;
+        }
+        if (wave < 4) {
+            QS_SYNC()  // barrier 2n
+        }
+    } else if (wave < 4) {
         // ---- group A: half k in interval k ----
         int buf = 0;
 #pragma unroll 1
