@@ -575,17 +575,65 @@ __global__ __launch_bounds__(256) void kth_select(const float* __restrict__ samp
     }
     const float* s = sample_scores + (int64_t)q * sample_ld;
     const int qc = (query_coll && q < n_queries) ? query_coll[q] : -1;
-    // a lower bound of the kk-th sample score is as good a threshold as the score itself
-    const uint32_t key = block_coarse_select(
-        [&](int i) {
-            float v = s[i];
-            if (qc != -1) {
-                const int64_t row = (int64_t)(i / unit) * stride * unit + i % unit;
-                if (row >= n_docs || doc_coll[row] != qc) v = -INFINITY;
+    auto val = [&](int i) {
+        float v = s[i];
+        if (qc != -1) {
+            const int64_t row = (int64_t)(i / unit) * stride * unit + i % unit;
+            if (row >= n_docs || doc_coll[row] != qc) v = -INFINITY;
+        }
+        return v;
+    };
+    // Any threshold near the kk-th sample score serves (the certificate only needs "the scan
+    // emitted every row >= tau"), and kk is a fraction of a percent of the sample.  Fast path:
+    // with M the largest sample score, only the values in [M/2, M] are binned (4096 linear
+    // bins: a handful of LDS atomics instead of one per sample, most of which would collide on
+    // the two or three exponent bins around zero); when at least kk of them sit there, tau is
+    // the lower edge of the bin that holds the kk-th.  Otherwise (M <= 0, or a sample that is
+    // not bell-shaped) the two-pass key select below decides.
+    __shared__ float kred[4];
+    __shared__ int kcnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto sweep = [&](auto&& fn) {   // 8 loads in flight per thread
+        for (int base = threadIdx.x; base < n_sample; base += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = base + u * 256 < n_sample ? val(base + u * 256) : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fn(v[u]);
+        }
+    };
+    float m = -INFINITY;
+    sweep([&](float v) { m = fmaxf(m, v); });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, WAVE));
+    if (lane == 0) kred[wave] = m;
+    if (threadIdx.x == 0) kcnt = 0;
+    for (int i = threadIdx.x; i < CS_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    m = fmaxf(fmaxf(kred[0], kred[1]), fmaxf(kred[2], kred[3]));
+    if (m > 0.f && m < INFINITY) {
+        const float thr = 0.5f * m, scale = 4095.f / (m - thr);
+        int c = 0;
+        sweep([&](float v) {
+            if (v >= thr) {
+                const int bn = (int)((v - thr) * scale);
+                atomicAdd(&hist[bn > CS_BINS - 1 ? CS_BINS - 1 : bn], 1);
+                ++c;
             }
-            return fkey(v);
-        },
-        n_sample, kk, hist, aux);
+        });
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, WAVE);
+        if (lane == 0 && c) atomicAdd(&kcnt, c);
+        __syncthreads();
+        if (kcnt >= kk) {   // (block-uniform)
+            coarse_find_bin(hist, kk, aux);
+            if (threadIdx.x == 0) tau[q] = thr + (float)aux[0] / scale;
+            return;
+        }
+        __syncthreads();
+    }
+    // a lower bound of the kk-th sample score is as good a threshold as the score itself
+    const uint32_t key = block_coarse_select([&](int i) { return fkey(val(i)); }, n_sample, kk, hist, aux);
     if (threadIdx.x == 0) tau[q] = coarse_value(key);
 }
 
@@ -608,8 +656,8 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
 //
 //  band    the candidates that can still reach the top-k: with a_k the k-th largest scan score,
 //          k rows have true cosine >= a_k/||q|| - eps, so a row whose scan score is below
-//          a_k - 2*eps*||q|| cannot beat them.  a_k is replaced by the two-pass lower bound of
-//          block_coarse_select (a slightly wider band, never a narrower one); the first 16
+//          a_k - 2*eps*||q|| cannot beat them.  a_k is replaced by a lower bound from one
+//          histogram pass (a slightly wider band, never a narrower one); the first 16
 //          candidates per thread stay in registers across the passes.
 //  rescore float64 SEQUENTIAL sums (the oracle's contract), one lane per row, rows dealt
 //          round-robin to the 4 waves.  Each wave stages its rows through its own LDS tile, 32
@@ -620,8 +668,10 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
 constexpr int SEL_THREADS = 256;
 constexpr int RS_ROWS = 32;        // rows per wave per batch
 constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
-constexpr int SEL_REG = 16;        // candidates per thread kept in registers
+constexpr int SEL_REG = 24;        // candidates per thread kept in registers (6144 per query; the scan aims at <= 4096)
+constexpr int RS_DEPTH = 4;        // 32-dim chunks of a row in flight per wave (dim / 32 is a multiple)
 constexpr int SEL_BIG_BAND = 1024; // band capacity of the second-chance launch
+constexpr int SEL_FLAT = 8192;     // candidates of the per-lane segments addressed through a flat LDS index
 static size_t select_lds_bytes(int dim) {
     const size_t stage = sizeof(float4) * 4 * RS_ROWS * RS_STRIDE, hist = sizeof(int) * CS_BINS;
     return sizeof(float) * dim + (stage > hist ? stage : hist);
@@ -632,7 +682,7 @@ static size_t select_lds_bytes(int dim) {
 // (redo_flags != nullptr: workgroups of certified or overflowed queries exit at once) before the
 // exhaustive path is asked.
 template <int CAPB>
-__global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
+__global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
     const float* __restrict__ queries, const float* __restrict__ tau,
     const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
@@ -664,14 +714,13 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     //   nseg == 0  one flat list of cand_cnt[q] entries (K3b's output): thread t takes t, t+256, ..
     //   nseg  > 0  dense_scan_f16q's layout: nseg segments of seg_cap slots, segment s filled by
     //              ONE lane of the scan with cand_cnt[q * nseg + s] entries (a count above seg_cap
-    //              means entries were dropped).  nseg <= 256: 256 / nseg threads share a segment;
-    //              nseg <= 1024: a thread takes segments t, t + 256, t + 512, t + 768 (its first
-    //              my_n0 items come from the first, the next my_nx[0] from the second, ...).
-    const Cand* my_ptr;
-    const Cand* my_ptr1 = nullptr;
-    int my_stride, my_n, my_n0, my_nx[3] = {0, 0, 0};
-    bool overflow;
+    //              means entries were dropped).  Up to SEL_FLAT candidates are addressed through
+    //              src_off, a flat index of the filled slots: thread t takes items t, t+256, ..
+    const Cand* my_ptr = c + threadIdx.x;
+    int my_n, my_c[4] = {0, 0, 0, 0};
+    bool overflow, flat = true;
     int n;
+    __shared__ unsigned short src_off[SEL_FLAT];
     if (nseg == 0) {
         const int cnt = cand_cnt[q];
         overflow = cnt > CAND_CAP || tile_cnt[q / qtile] > tile_cap;
@@ -681,49 +730,62 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         // gathers, the rc 134 abort of gpurun_out/t1.log.  An overflowed query is never
         // certified; thr_dense_rescue redoes it.)
         n = cnt < CAND_CAP ? cnt : CAND_CAP;
-        my_ptr = c + threadIdx.x;
-        my_stride = SEL_THREADS;
-        my_n = my_n0 = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
+        my_n = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
     } else {
-        const int tps = nseg <= SEL_THREADS ? SEL_THREADS / nseg : 1;   // host keeps nseg <= 4 * SEL_THREADS
-        const int sg = threadIdx.x / tps, r = threadIdx.x % tps;
-        int sc = sg < nseg ? cand_cnt[(int64_t)q * nseg + sg] : 0;
-        bool over = sc > seg_cap;
-        sc = sc < seg_cap ? sc : seg_cap;
-        my_ptr = c + (int64_t)sg * seg_cap + r;
-        my_stride = tps;
-        my_n0 = sc > r ? (sc - r + tps - 1) / tps : 0;
-        my_n = my_n0;
+        // thread t owns segments t, t + 256, t + 512, t + 768 (host keeps nseg <= 4 * SEL_THREADS);
+        // the flat order is thread-major: an exclusive scan of the per-thread totals places them
+        __shared__ int wtot[4];
+        bool over = false;
+        int tot = 0;
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {   // (extra segments only when tps == 1)
-            int s2 = sg + (x + 1) * SEL_THREADS < nseg ? cand_cnt[(int64_t)q * nseg + sg + (x + 1) * SEL_THREADS] : 0;
-            over |= s2 > seg_cap;
-            s2 = s2 < seg_cap ? s2 : seg_cap;
-            my_nx[x] = s2;
-            my_n += s2;
+        for (int x = 0; x < 4; ++x) {
+            const int sg = (int)threadIdx.x + x * SEL_THREADS;
+            int sc = sg < nseg ? cand_cnt[(int64_t)q * nseg + sg] : 0;
+            over |= sc > seg_cap;
+            my_c[x] = sc < seg_cap ? sc : seg_cap;
+            tot += my_c[x];
         }
-        my_ptr1 = c + (int64_t)(sg + SEL_THREADS) * seg_cap;
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wtot[wave] = incl;
         overflow = __syncthreads_or(over) != 0;
-        __shared__ int n_total;
-        if (threadIdx.x == 0) n_total = 0;
-        __syncthreads();
-        if (my_n) atomicAdd(&n_total, my_n);
-        __syncthreads();
-        n = n_total;
+        int base = incl - tot;
+        for (int x = 0; x < wave; ++x) base += wtot[x];
+        n = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        flat = n <= SEL_FLAT;
+        if (flat) {
+            // src_off[i] = slot of flat candidate i: the reads below are then coalesced (lane l
+            // of a wave takes flat item l + 64 * ..., i.e. neighbouring slots of a segment)
+            // instead of one segment per lane, which cost a cache line per lane and load
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int first = ((int)threadIdx.x + x * SEL_THREADS) * seg_cap;
+                for (int j = 0; j < my_c[x]; ++j) src_off[base + j] = (unsigned short)(first + j);
+                base += my_c[x];
+            }
+            __syncthreads();
+            my_n = n > (int)threadIdx.x ? (n - (int)threadIdx.x + SEL_THREADS - 1) / SEL_THREADS : 0;
+        } else {
+            my_n = tot;   // (rare: a threshold far too low) each thread walks its own segments
+        }
     }
     auto cand_at = [&](int u) -> Cand {
-        if (u < my_n0) return my_ptr[(int64_t)u * my_stride];
-        u -= my_n0;
-        const Cand* p = my_ptr1;
-        if (u >= my_nx[0]) {
-            u -= my_nx[0];
-            p += (int64_t)SEL_THREADS * seg_cap;
-            if (u >= my_nx[1]) {
-                u -= my_nx[1];
-                p += (int64_t)SEL_THREADS * seg_cap;
+        if (nseg == 0) return my_ptr[(int64_t)u * SEL_THREADS];
+        if (flat) return c[src_off[(int)threadIdx.x + u * SEL_THREADS]];
+        int sg = threadIdx.x;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+            if (u >= my_c[x]) {
+                u -= my_c[x];
+                sg += SEL_THREADS;
+            } else {
+                break;
             }
-        }
-        return p[u];
+        return c[(int64_t)sg * seg_cap + u];
     };
 
     // Collection filter (rag2_schema.sql:404-408): a candidate of another collection is read as
@@ -774,35 +836,66 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
     float floor32 = tau[q];
     bool band_done = false;
     if (n > k) {
-        // lower bound of the k-th largest scan score, two 12-bit passes
-        uint32_t prefix = 0;
-        int remaining = k;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int i = threadIdx.x; i < CS_BINS; i += SEL_THREADS) hist[i] = 0;
-            __syncthreads();
+        // a_k, a lower bound of the k-th largest scan score: ONE histogram pass over 4096 LINEAR
+        // bins between the smallest and the largest live candidate (the scores all sit just above
+        // tau: binned by float exponent, as the sample select does, they fall into two or three
+        // bins and the LDS atomics of a wave serialise on one address), then the smallest score
+        // of the bins that hold the k largest.  bin_of is monotone in the score (IEEE subtract,
+        // multiply by a positive constant, truncate), so those bins hold every score >= a_k.
+        __shared__ float fred[3][4];
+        float lo = INFINITY, hi = -INFINITY;
 #pragma unroll
-            for (int u = 0; u < SEL_REG; ++u) {
-                const uint32_t key = fkey(mine[u].score);
-                if (u < my_n && mine[u].score > -INFINITY) {
-                    if (pass == 0) atomicAdd(&hist[key >> 20], 1);
-                    else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
-                }
+        for (int u = 0; u < SEL_REG; ++u)
+            if (u < my_n && mine[u].score > -INFINITY) {
+                lo = fminf(lo, mine[u].score);
+                hi = fmaxf(hi, mine[u].score);
             }
-            for (int u = SEL_REG; u < my_n; ++u) {
-                const float sc = load_cand(u).score;
-                if (!(sc > -INFINITY)) continue;
-                const uint32_t key = fkey(sc);
-                if (pass == 0) atomicAdd(&hist[key >> 20], 1);
-                else if ((key >> 20) == (prefix >> 20)) atomicAdd(&hist[(key >> 8) & 4095], 1);
+        for (int u = SEL_REG; u < my_n; ++u) {
+            const float sc = load_cand(u).score;
+            if (sc > -INFINITY) {
+                lo = fminf(lo, sc);
+                hi = fmaxf(hi, sc);
             }
-            __syncthreads();
-            coarse_find_bin(hist, remaining, aux);
-            remaining -= aux[1];
-            prefix |= (uint32_t)aux[0] << (pass == 0 ? 20 : 8);
-            __syncthreads();
         }
-        const float a_k = coarse_value(prefix);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, WAVE));
+            hi = fmaxf(hi, __shfl_xor(hi, o, WAVE));
+        }
+        if (lane == 0) fred[0][wave] = lo, fred[1][wave] = hi;
+        for (int i = threadIdx.x; i < CS_BINS; i += SEL_THREADS) hist[i] = 0;
+        __syncthreads();
+        lo = fminf(fminf(fred[0][0], fred[0][1]), fminf(fred[0][2], fred[0][3]));
+        hi = fmaxf(fmaxf(fred[1][0], fred[1][1]), fmaxf(fred[1][2], fred[1][3]));
+        const float scale = hi - lo > 1e-30f ? 4095.f / (hi - lo) : 0.f;
+        auto bin_of = [&](float sc) {
+            const int bn = (int)((sc - lo) * scale);
+            return bn > CS_BINS - 1 ? CS_BINS - 1 : bn;
+        };
+#pragma unroll
+        for (int u = 0; u < SEL_REG; ++u)
+            if (u < my_n && mine[u].score > -INFINITY) atomicAdd(&hist[bin_of(mine[u].score)], 1);
+        for (int u = SEL_REG; u < my_n; ++u) {
+            const float sc = load_cand(u).score;
+            if (sc > -INFINITY) atomicAdd(&hist[bin_of(sc)], 1);
+        }
+        __syncthreads();
+        coarse_find_bin(hist, k, aux);
+        const int kbin = aux[0];
+        float a_k = INFINITY;
+#pragma unroll
+        for (int u = 0; u < SEL_REG; ++u)
+            if (u < my_n && mine[u].score > -INFINITY && bin_of(mine[u].score) >= kbin)
+                a_k = fminf(a_k, mine[u].score);
+        for (int u = SEL_REG; u < my_n; ++u) {
+            const float sc = load_cand(u).score;
+            if (sc > -INFINITY && bin_of(sc) >= kbin) a_k = fminf(a_k, sc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a_k = fminf(a_k, __shfl_xor(a_k, o, WAVE));
+        if (lane == 0) fred[2][wave] = a_k;
+        __syncthreads();
+        a_k = fminf(fminf(fred[2][0], fred[2][1]), fminf(fred[2][2], fred[2][3]));
         const float band = (float)((double)a_k - 2.5 * eps * qn_hi);
         const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
         if (band_lo > -INFINITY) {
@@ -890,33 +983,42 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_rescore(
         }
         const int jm = b0 + wave + 4 * lane;  // this lane's own row (lanes 0..31)
         const bool has_row = lane < RS_ROWS && jm < ns;
-        f32x4 nxt[4];
+        // RS_DEPTH chunks of every row in flight per wave (registers): the loop is bound by the
+        // latency of these gathers, not by the float64 chain
+        f32x4 nxt[RS_DEPTH][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = docs4[off[u]];
+        for (int dd = 0; dd < RS_DEPTH; ++dd)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[dd][u] = docs4[off[u] + 8 * dd];   // (nchunk >= RS_DEPTH)
         double dot = 0.0;
 #pragma unroll 1
-        for (int ck = 0; ck < nchunk; ++ck) {
+        for (int ck0 = 0; ck0 < nchunk; ck0 += RS_DEPTH) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[u];
-            const int cn = ck + 1 < nchunk ? ck + 1 : ck;  // the last trip re-requests its own chunk
+            for (int dd = 0; dd < RS_DEPTH; ++dd) {
+                const int ck = ck0 + dd;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = docs4[off[u] + 8 * cn];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const f32x4* src = q_lane ? qv4 + 8 * ck : stage + (lane & (RS_ROWS - 1)) * RS_STRIDE;
-            const f32x4* qv = qv4 + 8 * ck;
-            double acc = q_lane ? qq : dot;
+                for (int u = 0; u < 4; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[dd][u];
+                // (the last trips re-request the last chunk)
+                const int cn = ck + RS_DEPTH < nchunk ? ck + RS_DEPTH : nchunk - 1;
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                const f32x4 x = src[ch], y = qv[ch];
-                acc = __dadd_rn(acc, __dmul_rn((double)x.x, (double)y.x));
-                acc = __dadd_rn(acc, __dmul_rn((double)x.y, (double)y.y));
-                acc = __dadd_rn(acc, __dmul_rn((double)x.z, (double)y.z));
-                acc = __dadd_rn(acc, __dmul_rn((double)x.w, (double)y.w));
+                for (int u = 0; u < 4; ++u) nxt[dd][u] = docs4[off[u] + 8 * cn];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const f32x4* src = q_lane ? qv4 + 8 * ck : stage + (lane & (RS_ROWS - 1)) * RS_STRIDE;
+                const f32x4* qv = qv4 + 8 * ck;
+                double acc = q_lane ? qq : dot;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    const f32x4 x = src[ch], y = qv[ch];
+                    acc = __dadd_rn(acc, __dmul_rn((double)x.x, (double)y.x));
+                    acc = __dadd_rn(acc, __dmul_rn((double)x.y, (double)y.y));
+                    acc = __dadd_rn(acc, __dmul_rn((double)x.z, (double)y.z));
+                    acc = __dadd_rn(acc, __dmul_rn((double)x.w, (double)y.w));
+                }
+                if (q_lane) qq = acc; else dot = acc;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            if (q_lane) qq = acc; else dot = acc;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
         if (q_lane && b0 == 0) s_qn = __dsqrt_rn(qq);
         if (has_row) s_s[jm] = dot;  // the raw dot product for now
@@ -1009,7 +1111,7 @@ __global__ __launch_bounds__(EX_THREADS) void exact_slab_topk(
         for (int i = threadIdx.x; i < dim; i += EX_THREADS) lds_qv[i] = queries[(int64_t)q * dim + i];
         __syncthreads();
         if (threadIdx.x == 0) s_qn = __dsqrt_rn(seq_dot_f64(lds_qv, lds_qv, dim));
-        BlockTopK<EX_CAP> tk;
+        BlockTopK<EX_CAP, EX_THREADS> tk;
         tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k);
         const double qn = s_qn;
         const int qc = query_coll ? query_coll[q] : -1;
@@ -1058,7 +1160,7 @@ __global__ __launch_bounds__(256) void merge_lists(const double* __restrict__ in
     __shared__ double t_s;
     __shared__ int64_t t_id;
     const int q = blockIdx.x;
-    BlockTopK<EX_CAP> tk;
+    BlockTopK<EX_CAP, EX_THREADS> tk;
     tk.init(b_s, b_id, &b_cnt, &t_s, &t_id, k_out);
     const int total = n_lists * k_in;
     for (int base = 0; base < total; base += blockDim.x) {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
     __threadfence_block();
 
     // ---- segmented left-to-right sums + top-k ----
-    BlockTopK<GR_CAP> tk;
+    BlockTopK<GR_CAP, GR_THREADS> tk;
     tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);
     for (int base = 0; base < nc; base += GR_THREADS) {
         const int i = base + threadIdx.x;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(GR_THREADS) void graph_fallback_kernel(
             }
             __syncthreads();
         }
-        BlockTopK<GrFull::CAP> tk;
+        BlockTopK<GrFull::CAP, GR_THREADS> tk;
         tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);
         for (int64_t base = 0; base < n_chunks; base += GR_THREADS) {
             const int64_t c = base + threadIdx.x;

@@ -101,15 +101,25 @@ __device__ __forceinline__ int next_pow2(int v) {
     return p;
 }
 
-// Streaming block top-k: threads push (score,id) pairs that beat the current
-// k-th best; when the LDS buffer fills it is sorted and cut back to k.
-// All threads of the block must call push()/flush_if_needed() together.
-template <int CAP>
+// Streaming block top-k: threads push (score,id) pairs that beat the current threshold; when the
+// LDS buffer fills it is cut back.  All threads of the block (THREADS of them) must call push() /
+// compact() / finish() together.
+//
+// compact() does NOT sort (a 1024-entry bitonic sort of (double, int64) pairs is 55 barrier
+// stages -- profiling the BM25 kernel showed it spending more than half of a short query's time
+// there): a 4-pass radix select over the top 32 bits of the order-preserving score key finds the
+// prefix P of the k-th best score, the entries with prefix >= P are kept (at least k: the k best
+// and the few that share the k-th's sign, exponent and 20 mantissa bits), and the threshold
+// becomes the smallest score with that prefix -- a LOWER bound of the k-th best, which is all a
+// pruning threshold has to be.  Should that not free a block's worth of slots (a flood of
+// near-equal scores), the exact sort-and-cut runs instead.  finish() sorts what is left, exactly.
+template <int CAP, int THREADS>
 struct BlockTopK {
+    static constexpr int PER = (CAP + THREADS - 1) / THREADS;   // buffer entries per thread (blockDim.x == THREADS)
     double* s;     // [CAP] LDS
     int64_t* id;   // [CAP] LDS
     int* count;    // LDS
-    double* thr_s; // LDS: k-th best so far (score)
+    double* thr_s; // LDS: lower bound of the k-th best so far (score)
     int64_t* thr_id;
     int k;
 
@@ -129,18 +139,132 @@ struct BlockTopK {
     // Call with valid=false for threads that have nothing this round.
     // Precondition (kept by compact()): count + blockDim.x <= CAP.
     __device__ void push(bool valid, double sc, int64_t i) {
-        if (valid && better(sc, i, *thr_s, *thr_id)) {
-            int p = atomicAdd(count, 1);
-            s[p] = sc;
-            id[p] = i;
+        // one LDS atomic per wave (not per entry: they all hit the same address)
+        const bool ok = valid && better(sc, i, *thr_s, *thr_id);
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+            const int lane = threadIdx.x & (WAVE - 1);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(count, __popcll(m));
+            base = __shfl(base, 0, WAVE);
+            if (ok) {
+                const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+                s[p] = sc;
+                id[p] = i;
+            }
         }
         __syncthreads();
         if (*count + (int)blockDim.x > CAP) compact();
     }
     __device__ void compact() {
+        __shared__ int hist[256];
+        __shared__ int sel[2];      // bin of the k-th, entries in the bins above it
+        __shared__ int kept;
+        const int c = *count;       // (uniform: read after a barrier by every caller)
+        if (c < k) return;
+        const int lane = threadIdx.x & (WAVE - 1);
+        uint32_t prefix = 0;
+        int remaining = k;
+#pragma unroll 1
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < c; i += blockDim.x) {
+                const uint32_t key = (uint32_t)(dkey(s[i]) >> 32);
+                if (shift == 24 || (key >> (shift + 8)) == (prefix >> (shift + 8)))
+                    atomicAdd(&hist[(key >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x < WAVE) {   // lane l owns bins 255 - 4l .. 252 - 4l, largest first
+                const int top = 255 - 4 * lane;
+                const int h0 = hist[top], h1 = hist[top - 1], h2 = hist[top - 2], h3 = hist[top - 3];
+                const int mine = h0 + h1 + h2 + h3;
+                int incl = mine;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int v = __shfl_up(incl, o, WAVE);
+                    if (lane >= o) incl += v;
+                }
+                const int excl = incl - mine;
+                if (excl < remaining && remaining <= incl) {
+                    int cum = excl, bin = top;
+                    if (cum + h0 < remaining) {
+                        cum += h0; bin = top - 1;
+                        if (cum + h1 < remaining) {
+                            cum += h1; bin = top - 2;
+                            if (cum + h2 < remaining) { cum += h2; bin = top - 3; }
+                        }
+                    }
+                    sel[0] = bin;
+                    sel[1] = cum;
+                }
+            }
+            __syncthreads();
+            prefix |= (uint32_t)sel[0] << shift;
+            remaining -= sel[1];
+        }
+        // keep the entries whose prefix is >= that of the k-th best, packed to the front
+        double rs[PER];
+        int64_t ri[PER];
+        bool keep[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = (int)threadIdx.x + u * (int)blockDim.x;
+            keep[u] = false;
+            if (i < c) {
+                rs[u] = s[i];
+                ri[u] = id[i];
+                keep[u] = (uint32_t)(dkey(rs[u]) >> 32) >= prefix;
+            }
+        }
+        if (threadIdx.x == 0) kept = 0;
+        __syncthreads();   // every entry is in a register before any slot is overwritten
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const unsigned long long m = __ballot(keep[u]);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&kept, __popcll(m));
+                base = __shfl(base, 0, WAVE);
+                if (keep[u]) {
+                    const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+                    s[p] = rs[u];
+                    id[p] = ri[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int nk = kept;
+        if (nk + (int)blockDim.x > CAP) {   // not enough room won: the exact cut, on the original entries
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int i = (int)threadIdx.x + u * (int)blockDim.x;
+                if (i < c) {
+                    s[i] = rs[u];
+                    id[i] = ri[u];
+                }
+            }
+            __syncthreads();
+            sort_and_cut();
+            return;
+        }
+        for (int i = nk + (int)threadIdx.x; i < c; i += blockDim.x) {
+            s[i] = -INFINITY;
+            id[i] = INT64_MAX;
+        }
+        if (threadIdx.x == 0) {
+            *count = nk;
+            *thr_s = dkey_inv((uint64_t)prefix << 32);   // smallest score with this prefix
+            *thr_id = INT64_MAX;                          // (a score equal to it still passes)
+        }
+        __syncthreads();
+    }
+    // exact: sorted best-first, cut to k, threshold = the k-th best itself
+    __device__ void sort_and_cut() {
         // slots past *count hold (-inf, INT64_MAX) already: sort only the occupied power of two
         int c = *count;
         int n2 = next_pow2(c < 2 ? 2 : c);
+        __syncthreads();
         bitonic_sort_desc_n(s, id, n2 < CAP ? n2 : CAP);
         __syncthreads();
         for (int i = threadIdx.x; i < CAP; i += blockDim.x)
@@ -159,7 +283,7 @@ struct BlockTopK {
     }
     // Final: sorted best-first in s/id[0..n), returns n = min(k, pushed).
     __device__ int finish() {
-        compact();
+        sort_and_cut();
         return *count;
     }
 };
