@@ -256,39 +256,20 @@ def test_bm25_matches_oracle(T):
     assert int(cnt[3]) == 0
 
 
-def test_bm25_chip_filling_batch_uses_the_small_block_shape(T):
-    """More than two queries per CU switch thr_bm25_topk to its 256-thread / 4096-id shape (four
-    queries per CU); the tests above run the 512-thread / 8192-id one.  Same bits either way:
-    stop words (lists of many passes), rare terms, repeated and empty queries, with and without
-    the bounds, conjunctive, filtered -- 640 queries against the oracle."""
-    from triple_hybrid_rag_amd import synth
-    n, nq = 20000, 640
-    csr, idf, avgdl, v = lexical_fixture(T, n)
-    idx = T.GpuIndex().set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
-    coll = (np.arange(n) * 7919 % 10).astype(np.int32)
-    idx.set_collections(coll)
-    qt = synth.lexical_queries(nq, csr.df_local, 4)
-    rare = csr.df_local.copy()
-    rare[rare > 50] = 0
-    qt[320:] = synth.lexical_queries(nq - 320, rare, 4)
-    top = np.argsort(-csr.df_local)[:4].astype(np.int32)
-    qt[0] = top
-    qt[1] = [top[0], top[0], -1, top[1]]
-    qt[2] = -1
-    qd = dev(qt)
-    Se, Ie = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
-    for prune in (True, False):
-        S, I, cnt = idx.bm25_search(qd, 50, prune=prune)
-        assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"bm25 small shape prune={prune}")
-    Sa, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
-                         conjunctive=True)
-    S, I, cnt = idx.bm25_search(qd, 50, conjunctive=True)
-    assert_topk_equal(S, I, cnt, Sa, Ia, [len(s) for s in Sa], "bm25 small shape AND")
-    qc = (np.arange(nq) % 11 - 1).astype(np.int32)   # -1 (no filter) and collections 0..9
-    Sf, If = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
-                         doc_coll=coll, query_coll=qc)
-    S, I, cnt = idx.bm25_search(qd, 50, collections=dev(qc))
-    assert_topk_equal(S, I, cnt, Sf, If, [len(s) for s in Sf], "bm25 small shape filtered")
+def test_bm25_small_block_shape_in_a_subprocess():
+    """THR_BM25_SHAPE=small (256 threads / 4096 staged ids, four queries per CU) is read once per
+    process: the two BM25 tests of this file run again under it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("THR_BM25_SHAPE") == "small":
+        pytest.skip("already inside the small-shape run")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "test_bm25_matches_oracle or test_bm25_pruning_and_filters_stay_exact"],
+                         env=dict(os.environ, THR_BM25_SHAPE="small"), cwd=root, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
 def test_bm25_pruning_and_filters_stay_exact(T):

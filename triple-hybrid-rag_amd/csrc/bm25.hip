@@ -9,12 +9,16 @@
 //
 // One workgroup per query.  Posting lists are doc-sorted, so a doc's score is
 // assembled by its OWNER posting -- the posting of the first query term that
-// contains the doc -- which binary-searches the later terms' lists.  That
-// gives the fixed summation order with no atomics and no hash table.  The doc
-// ids are staged in LDS (posting-block staging, in doc-range passes that always
-// fit) and the searches run there -- a search in HBM/L2 is a chain of ~13
-// dependent loads per term; term frequencies are read from memory only for the
-// postings that need them.
+// contains the doc.  That gives the fixed summation order with no atomics and
+// no hash table.  The doc ids are staged in LDS (posting-block staging, in
+// doc-range passes that always fit).  How a pass finds the owners depends on
+// its lists: dense lists (narrow doc range) OR a term bit into a doc-slot
+// mask; sparse lists set a Bloom bit per (list, doc) and a posting whose doc
+// shows in no other list's bits is scored at once (one contribution, no
+// search), the few others are searched from a dense work list; in between,
+// with a threshold to prune against, owners and the sum of their terms' score
+// bounds come from binary searches in LDS and only the survivors touch memory.
+// Term frequencies and doc lengths are read only for the postings that need them.
 // Algorithmic bytes per query: sum_t df_t * (4 doc + 4 tf + 4 doclen) + T * 16.
 #include <cstdlib>
 #include "thr_common.hpp"
@@ -114,7 +118,7 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
 // collection filter, term-frequency / doc-length gathers, float64 score, top-k push.  theta is
 // refreshed at the end of a pass when enough new docs have entered the buffer.
 template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP>
-__global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
+__global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
     const double* __restrict__ idf, const double* __restrict__ term_ub,
@@ -266,7 +270,10 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
                 }
                 surv[atomicAdd(&n_surv, 1)] = (uint16_t)slot;
             }
-        } else if (have_theta) {
+        } else if (have_theta && (last - first) < 32 * (int64_t)total) {
+            // moderately dense lists and a threshold to prune with: LDS-only owner / bound search,
+            // survivors to phase 2 (a doc is dropped on the sum of its terms' bounds before any
+            // gather; the sweep below would find most docs shared and score them all)
             for (int i = threadIdx.x; i < total; i += BM_THREADS) {
                 int t = 0;
                 while (i >= t_prefix[t + 1]) ++t;
@@ -288,17 +295,17 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
                 surv[atomicAdd(&n_surv, 1)] = (uint16_t)(tr[t].lds_off + off);
             }
         } else {
-            // no theta yet (the first pass of a query -- the only pass of a short one): nothing
-            // can be dropped, so every owner is scored in the same sweep that finds it.
+            // sparse lists (or no threshold yet): every owner is scored in the same sweep that finds it.
             // Sparse lists share few docs, so nearly every "is this doc in list e" question is
             // answered NO: a Bloom bit per (list, doc hash) in the idle scratch buffer answers
             // those with one LDS read instead of a binary search (a chain of ~11); a set bit is
             // confirmed by the search, so the result is exact.  The doc-length and own-tf gathers
             // of the NEXT sweep step are requested before the current one is worked on.
-            // bits per list: the largest power of two (<= 32768) that fits two thirds of the
-            // buffer nt times (the rest is the work list of sweep 2)
+            // bits per list: the largest power of two (<= 32768) that fits the buffer nt times next
+            // to a work list that could take every posting of the pass (16 bits each)
+            constexpr int SCR_WORDS = BM_WINDOW + BM_WINDOW / 2;
             int bwords = 1024;
-            while (bwords >= 128 && nt * bwords > BM_WINDOW) bwords >>= 1;
+            while (bwords >= 128 && nt * bwords + (total + 1) / 2 > SCR_WORDS) bwords >>= 1;
             const bool bloom = bwords >= 128;
             const int bl2 = 31 - __clz(bwords * 32);
             if (bloom) {
@@ -372,40 +379,48 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_topk_kernel(
             // bits is the doc's only posting (owner, one contribution) and is scored at once; the
             // few with a set bit -- which a wave would otherwise wait for, lane by lane -- go to a
             // work list (behind the bits in the same buffer) that sweep 2 walks densely.
-            uint16_t* work = reinterpret_cast<uint16_t*>(scratch + nt * bwords);
-            const int work_cap = bloom ? 2 * (BM_WINDOW + BM_WINDOW / 2 - nt * bwords) : 0;
+            static_assert(2 * (BM_WINDOW + BM_WINDOW / 2) >= BM_STAGE, "work list of a pass without the filter");
+            uint16_t* work = reinterpret_cast<uint16_t*>(bloom ? scratch + nt * bwords : scratch);
             if (threadIdx.x == 0) n_surv = 0;   // (work list length; phase 2 below sees 0 again)
             __syncthreads();
-            fetch(threadIdx.x);
-            for (int base = 0; base < total; base += BM_THREADS) {
-                const int i = base + threadIdx.x;
-                const int t = n_t, off = n_off;
-                const int32_t d = n_d, tf_own = n_tf;
-                const float dl_own = n_dl;
-                fetch(i + BM_THREADS);
-                bool owner = false;
-                double score = 0.0;
-                if (i < total) {
-                    bool alone = bloom;
-                    if (bloom) {
-                        const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
-                        for (int e = 0; e < nt; ++e)
-                            if (e != t && ((scratch[e * bwords + (h >> 5)] >> (h & 31)) & 1u)) alone = false;
-                    }
-                    if (alone) {
-                        owner = !(conjunctive && nt > 1) && !(qc != -1 && doc_coll[d] != qc);
-                        if (owner) score = __dadd_rn(score, bm25_contrib(t_idf[t], (double)tf_own, (double)dl_own, avgdl, k1, b));
-                    } else {
-                        int slot = work_cap;
-                        if (bloom) slot = atomicAdd(&n_surv, 1);
-                        if (slot < work_cap) work[slot] = (uint16_t)i;
-                        else owner = score_full(t, off, d, dl_own, tf_own, score);   // no list (or full): search here
+            if (bloom) {
+                // list by list: everything that depends on the term is uniform (scalar registers)
+                for (int t = 0; t < nt; ++t) {
+                    const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
+                    const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
+                    const int pre = __builtin_amdgcn_readfirstlane(t_prefix[t]);
+                    const int32_t* tf_t = post_tf + tr[t].lo + tr[t].cur;
+                    const double idf_t = t_idf[t], ub_t = t_ub[t];
+                    const bool single_ok = !(conjunctive && nt > 1);
+                    for (int base = 0; base < sub; base += BM_THREADS) {
+                        const int i = base + (int)threadIdx.x;
+                        bool owner = false;
+                        double score = 0.0;
+                        int32_t d = 0;
+                        if (i < sub) {
+                            d = st_doc[off0 + i];
+                            const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
+                            const uint32_t w = h >> 5, bit = 1u << (h & 31);
+                            bool alone = true;
+                            for (int e = 0; e < nt; ++e)
+                                if (e != t && (scratch[e * bwords + w] & bit)) alone = false;
+                            if (!alone) {
+                                work[atomicAdd(&n_surv, 1)] = (uint16_t)(pre + i);
+                            } else if (single_ok && !(ub_t < th_s) && !(qc != -1 && doc_coll[d] != qc)) {
+                                // (ub_t < threshold: no posting of this list can enter on its own)
+                                owner = true;
+                                score = __dadd_rn(score, bm25_contrib(idf_t, (double)tf_t[i], (double)doclen[d], avgdl, k1, b));
+                            }
+                        }
+                        tk.push(owner, score, (int64_t)d);
                     }
                 }
-                tk.push(owner, score, (int64_t)d);
+            } else {   // no room for the bits (many terms): every posting takes the searching sweep
+                for (int i = threadIdx.x; i < total; i += BM_THREADS) work[i] = (uint16_t)i;
+                if (threadIdx.x == 0) n_surv = total;
             }
             __syncthreads();
-            const int n_work = n_surv < work_cap ? n_surv : work_cap;
+            const int n_work = n_surv;
             fetch(threadIdx.x < n_work ? (int)work[threadIdx.x] : -1);
             for (int base = 0; base < n_work; base += BM_THREADS) {
                 const int j = base + threadIdx.x;
@@ -552,27 +567,18 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                       max_terms <= 0 || max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
                   THR_ERR_INVALID);
     THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
-    // Block shape.  Batches that fill the chip (more than two queries per CU) run 256 threads /
-    // 4096 staged ids per pass / 39 KiB of LDS: four queries per CU, and the fixed cost of a query
-    // (set-up, staging, the final sort) overlaps four ways -- 0.52 ms against 0.67 ms for the
-    // bench's 2048 four-term queries.  Small batches run 512 threads / 8192 ids / 75 KiB: with a
-    // CU to itself a query finishes twice as fast on twice the threads (12 ms against 23 ms for
-    // 256 stop-word queries of 560 K postings each).  THR_BM25_SHAPE=big|small forces one.
-    static int forced = -1;
-    if (forced < 0) {
+    // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two queries per CU --
+    // a four-term query of the bench (6.7 K postings) is one pass.  THR_BM25_SHAPE=small selects
+    // 256 threads / 4096 ids / 39 KiB, four queries per CU: the fixed cost of a query (set-up,
+    // staging, the final sort) overlaps four ways, which wins when every list is short (2048
+    // queries over lists of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise
+    // (bench mix 0.46 ms against 0.42 ms; 256 stop-word queries 23 ms against 12 ms).
+    static int small = -1;
+    if (small < 0) {
         const char* e = getenv("THR_BM25_SHAPE");
-        forced = !e ? 0 : e[0] == 'b' ? 1 : e[0] == 's' ? 2 : 0;
+        small = (e && e[0] == 's') ? 1 : 0;
     }
-    int cus = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        static int cached = 0;
-        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cached = prop.multiProcessorCount;
-        if (cached > 0) cus = cached;
-    }
-    const bool big = forced == 1 || (forced == 0 && n_queries <= 2 * cus);
+    const bool big = !small;
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(n_queries), dim3(T), 0, (hipStream_t)stream, \
                        rowptr, post_doc, post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr, \
