@@ -1362,13 +1362,16 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     // on average; aim at 4096 (a quarter of CAND_CAP, half of a tile list's share).  ks is capped
     // at 64: the count of passing rows then spreads by ~1/8 of its mean (the tile share is 8
     // sigma away), and the sample pass + select cost a third of what ks = k' = 192 did.
-    p.ksample = kprime < 64 ? kprime : 64;
+    // The register-resident scan keeps one candidate segment per lane (no shared tile list), so
+    // only the cost matters there: ks = 32 (spread ~1/6) halves the sample pass and the select.
+    const int ks_cap = p.qreg ? 32 : 64;
+    p.ksample = kprime < ks_cap ? kprime : ks_cap;
     // (the sample must grow with the corpus: a capped sample lets n / S * ks rows through, which
     // overflows the candidate lists of every query on a 10M-row shard)
     // The sample pass costs ~ n * ks / aim, the scan's emit + K4's candidate read ~ aim: at 1M rows
     // the two meet at aim = 4096 (profiles/r2_scan_tau_experiment.json), so aim follows sqrt(n)
     // below that; never under 8 k' (k' = 128: 1024 = k' + 7 sigma of the passing count at ks = 64).
-    double aim = 4096.0 * sqrt((double)n_docs / 1.0e6);
+    double aim = (p.qreg ? 2896.0 : 4096.0) * sqrt((double)n_docs / 1.0e6);   // (ks / 64 under the root)
     const double aim_lo = 8.0 * kprime < 4096.0 ? 8.0 * kprime : 4096.0;
     aim = aim < aim_lo ? aim_lo : aim > 4096.0 ? 4096.0 : aim;
     int64_t target = (int64_t)((double)n_docs * (double)p.ksample / aim);
