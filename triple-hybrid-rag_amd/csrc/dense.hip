@@ -668,7 +668,7 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
 constexpr int SEL_THREADS = 256;
 constexpr int RS_ROWS = 32;        // rows per wave per batch
 constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
-constexpr int SEL_REG = 24;        // candidates per thread kept in registers (6144 per query; the scan aims at <= 4096)
+constexpr int SEL_REG = 16;        // candidates per thread kept in registers (4096 per query; the scan aims at ~2900)
 constexpr int RS_DEPTH = 4;        // 32-dim chunks of a row in flight per wave (dim / 32 is a multiple)
 constexpr int SEL_BIG_BAND = 1024; // band capacity of the second-chance launch
 constexpr int SEL_FLAT = 8192;     // candidates of the per-lane segments addressed through a flat LDS index
@@ -901,11 +901,17 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
         if (band_lo > -INFINITY) {
             // count and collect in one sweep; past CAPB rows only the count matters
 #pragma unroll
-            for (int u = 0; u < SEL_REG; ++u)
-                if (u < my_n && mine[u].score >= band_lo) {
-                    const int p = atomicAdd(&n_sel, 1);
-                    if (p < CAPB) s_id[p] = mine[u].doc;
+            for (int u = 0; u < SEL_REG; ++u) {   // (one LDS atomic per wave and register slot)
+                const bool in = u < my_n && mine[u].score >= band_lo;
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&n_sel, __popcll(m));
+                    base = __shfl(base, 0, WAVE);
+                    const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (in && p < CAPB) s_id[p] = mine[u].doc;
                 }
+            }
             for (int u = SEL_REG; u < my_n; ++u) {
                 const Cand e = load_cand(u);
                 if (e.score >= band_lo) {   // (band_lo > -inf: filtered candidates never pass)
@@ -972,6 +978,8 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     const bool q_lane = wave == 3 && lane == 63;  // accumulates ||q||^2 instead of a row
     const int cpr = dim / 4, nchunk = dim / 32;
     double qq = 0.0;
+    // (the row norm of this thread's first shortlist slot: requested now, used after the loop)
+    const double dn_first = (int)threadIdx.x < ns ? dnorm[s_id[threadIdx.x]] : 0.0;
     for (int b0 = 0; b0 < ns || (b0 == 0 && q_lane); b0 += 4 * RS_ROWS) {
         // shortlist slot of (wave, staged row r) is b0 + wave + 4 r; loader rows lrow + 8 u
         int64_t off[4];
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     __syncthreads();
     for (int p = threadIdx.x; p < ns; p += SEL_THREADS) {
         const int64_t row = s_id[p];
-        const double qn = s_qn, dn = dnorm[row], dot = s_s[p];
+        const double qn = s_qn, dn = p == (int)threadIdx.x ? dn_first : dnorm[row], dot = s_s[p];
         double sim = -INFINITY;
         if (dn > 0.0) sim = qn > 0.0 ? __ddiv_rn(dot, __dmul_rn(qn, dn)) : 0.0;
         s_s[p] = sim;
