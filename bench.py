@@ -228,8 +228,11 @@ def main():
 
     FLAVOURS = ("f16-inline", "f16", "f32")
     KERNEL = {"f32": f"dense_scan_mfma2<dim={args.dim},MODE_FILTER>",
-              "f16": f"dense_scan_f16q{'s' if args.dim <= 768 else ''}<dim={args.dim},MODE_FILTER> "
-                     "(queries in registers, fragment-major f16 rows through LDS-DMA)",
+              "f16": (f"dense_scan_f16qs<dim={args.dim},MODE_FILTER,{os.environ.get('THR_DENSE_MFMA', '16')}> "
+                      "(v_mfma_f32_16x16x32_f16 unless THR_DENSE_MFMA=32; " if args.dim <= 768 and
+                      os.environ.get("THR_DENSE_F16") != "q" else
+                      f"dense_scan_f16q<dim={args.dim},MODE_FILTER> (v_mfma_f32_32x32x16_f16; ") +
+                     "queries in registers, fragment-major f16 rows through LDS-DMA)",
               "f16-inline": f"dense_scan_f16<dim={args.dim},MODE_FILTER> (float32 rows rounded in flight)"}
 
     def set_flavour(name):
