@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 3
+#define THR_ABI_VERSION 4
 
 typedef void *thr_stream_t;
 
@@ -252,6 +252,13 @@ int thr_maxsim(const uint16_t *qtok /* f16 [nq,q_tokens,tok_dim] */, int n_queri
                const uint16_t *dtok /* f16 [n_docs,d_tokens,tok_dim], or its packed image */,
                int64_t n_docs, int d_tokens, int tok_dim, const int32_t *cand, int n_cand,
                float *out_scores /* [nq,n_cand] */, int dtok_packed, thr_stream_t stream);
+/* The same with the candidates as GLOBAL ids (what thr_rrf_fuse returns) of a shard whose local
+ * doc 0 has id id_base: local = id - id_base; negative ids and ids of other shards score -inf.
+ * (Saves the caller the id arithmetic: nine elementwise launches per batch in PyTorch.) */
+int thr_maxsim_ids(const uint16_t *qtok, int n_queries, int q_tokens, const uint16_t *dtok,
+                   int64_t n_docs, int d_tokens, int tok_dim, const int64_t *cand_ids /* [nq,n_cand] */,
+                   int64_t id_base, int n_cand, float *out_scores, int dtok_packed,
+                   thr_stream_t stream);
 /* Ordering after the rerank (retrieval.py:449-455): candidate p of query q gets the maximum of
  * scores[l][q][p] over the n_lists lists (document-sharded index: the shard that owns the
  * candidate wrote its MaxSim score, the others -inf; list_stride in floats, 0 = n_queries * n),

@@ -546,6 +546,15 @@ def test_maxsim_matches_oracle(T):
     packed = T._native.maxsim_pack(dev(dt))
     got_p = T._native.maxsim(dev(qt), packed, dev(cand), packed=True).cpu().numpy().astype(np.float64)
     assert np.array_equal(got, got_p)        # same products, same accumulation order
+    # thr_maxsim_ids: the same candidates as global ids of a shard that starts at id 7000; ids of
+    # other shards (below the base, past the end) and negative ids score -inf
+    gids = cand.astype(np.int64) + 7000
+    gids[0, 5] = -1
+    gids[1, 0], gids[1, 1] = 6999, 7300
+    got_g = T._native.maxsim_ids(dev(qt), packed, dev(gids), 7000, packed=True).cpu().numpy().astype(np.float64)
+    assert got_g[1, 0] == -np.inf and got_g[1, 1] == -np.inf and got_g[0, 5] == -np.inf
+    got_g[1, :2] = got[1, :2]
+    assert np.array_equal(got_g, got)
     exp = CO.maxsim(qt, dt, cand)
     assert got[0, 5] == -np.inf and exp[0, 5] == -np.inf
     ok = np.isfinite(exp)

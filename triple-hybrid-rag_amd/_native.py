@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -69,6 +69,7 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp]),
     "thr_rerank_order": (_i32, [_vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
+    "thr_maxsim_ids": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _vp]),
     "thr_maxsim_pack": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "thr_merge_topk": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
 }
@@ -511,6 +512,25 @@ def maxsim(qtok: torch.Tensor, dtok: torch.Tensor, cand: torch.Tensor,
     out = torch.empty(cand.shape, dtype=torch.float32, device=qtok.device)
     _check(load().thr_maxsim(pq, nq, qt, pdt, nd, dt, td, pc, cand.shape[1], out.data_ptr(),
                              1 if packed else 0, _stream()), "thr_maxsim")
+    return out
+
+
+def maxsim_ids(qtok: torch.Tensor, dtok: torch.Tensor, cand_ids: torch.Tensor, id_base: int,
+               packed: bool = False) -> torch.Tensor:
+    """cand_ids holds GLOBAL doc ids (int64) of a shard starting at ``id_base``; negative ids and
+    ids outside the shard score -inf."""
+    pq = _dev(qtok, torch.float16, "qtok", 3)
+    pdt = _dev(dtok, torch.float16, "dtok", 3)
+    pc = _dev(cand_ids, torch.int64, "cand_ids", 2)
+    nq, qt, td = qtok.shape
+    nd, dt, td2 = dtok.shape
+    if td != td2 or cand_ids.shape[0] != nq:
+        raise NativeError("maxsim: shape mismatch")
+    if qt % 32 or dt % 32 or td % 16:
+        raise NativeError("maxsim: q_tokens/d_tokens must be multiples of 32, tok_dim of 16")
+    out = torch.empty(cand_ids.shape, dtype=torch.float32, device=qtok.device)
+    _check(load().thr_maxsim_ids(pq, nq, qt, pdt, nd, dt, td, pc, int(id_base), cand_ids.shape[1],
+                                 out.data_ptr(), 1 if packed else 0, _stream()), "thr_maxsim_ids")
     return out
 
 

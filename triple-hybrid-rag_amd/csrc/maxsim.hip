@@ -56,15 +56,22 @@ __global__ __launch_bounds__(256) void maxsim_pack_kernel(const _Float16* __rest
 template <int KSTEPS, bool PACKED>
 __global__ __launch_bounds__(MS_THREADS) void maxsim_kernel(
     const _Float16* __restrict__ qtok, int q_tokens, const _Float16* __restrict__ dtok,
-    int64_t n_docs, int d_tokens, const int32_t* __restrict__ cand, int n_cand,
-    float* __restrict__ out) {
+    int64_t n_docs, int d_tokens, const int32_t* __restrict__ cand,
+    const int64_t* __restrict__ cand_ids, int64_t id_base, int n_cand, float* __restrict__ out) {
     constexpr int TD = KSTEPS * 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = blockIdx.y;
     const int c = blockIdx.x * MS_WAVES + wave;
     if (c >= n_cand) return;
-    const int32_t doc = cand[(int64_t)q * n_cand + c];
+    // local doc index: given directly, or as a global id of a shard that starts at id_base
+    int64_t doc;
+    if (cand_ids) {
+        const int64_t g = cand_ids[(int64_t)q * n_cand + c];
+        doc = g >= 0 ? g - id_base : -1;
+    } else {
+        doc = cand[(int64_t)q * n_cand + c];
+    }
     if (doc < 0 || doc >= n_docs) {
         if (lane == 0) out[(int64_t)q * n_cand + c] = -INFINITY;
         return;
@@ -127,11 +134,12 @@ extern "C" int thr_maxsim_pack(const uint16_t* dtok, int64_t n_docs, int d_token
     return launch_status();
 }
 
-extern "C" int thr_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, const uint16_t* dtok,
-                          int64_t n_docs, int d_tokens, int tok_dim, const int32_t* cand, int n_cand,
-                          float* out_scores, int dtok_packed, thr_stream_t stream) {
+static int launch_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, const uint16_t* dtok,
+                         int64_t n_docs, int d_tokens, int tok_dim, const int32_t* cand,
+                         const int64_t* cand_ids, int64_t id_base, int n_cand, float* out_scores,
+                         int dtok_packed, thr_stream_t stream) {
     clear_status();
-    THR_RETURN_IF(!qtok || !dtok || !cand || !out_scores, THR_ERR_INVALID);
+    THR_RETURN_IF(!qtok || !dtok || (!cand && !cand_ids) || !out_scores, THR_ERR_INVALID);
     THR_RETURN_IF(n_queries <= 0 || n_docs <= 0 || n_cand <= 0, THR_ERR_INVALID);
     THR_RETURN_IF(q_tokens <= 0 || q_tokens % 32 || d_tokens <= 0 || d_tokens % 32 ||
                       tok_dim <= 0 || tok_dim % 16 || tok_dim / 16 > MS_MAX_KSTEPS,
@@ -144,10 +152,12 @@ extern "C" int thr_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, con
     case KS:                                                                                     \
         if (dtok_packed)                                                                         \
             hipLaunchKernelGGL((maxsim_kernel<KS, true>), grid, dim3(MS_THREADS), 0, st, Q,      \
-                               q_tokens, Dk, n_docs, d_tokens, cand, n_cand, out_scores);        \
+                               q_tokens, Dk, n_docs, d_tokens, cand, cand_ids, id_base, n_cand,  \
+                               out_scores);                                                      \
         else                                                                                     \
             hipLaunchKernelGGL((maxsim_kernel<KS, false>), grid, dim3(MS_THREADS), 0, st, Q,     \
-                               q_tokens, Dk, n_docs, d_tokens, cand, n_cand, out_scores);        \
+                               q_tokens, Dk, n_docs, d_tokens, cand, cand_ids, id_base, n_cand,  \
+                               out_scores);                                                      \
         break;
     switch (tok_dim / 16) {
         THR_MS_CASE(1) THR_MS_CASE(2) THR_MS_CASE(4) THR_MS_CASE(6) THR_MS_CASE(8)
@@ -157,4 +167,20 @@ extern "C" int thr_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, con
     }
 #undef THR_MS_CASE
     return launch_status();
+}
+
+extern "C" int thr_maxsim(const uint16_t* qtok, int n_queries, int q_tokens, const uint16_t* dtok,
+                          int64_t n_docs, int d_tokens, int tok_dim, const int32_t* cand, int n_cand,
+                          float* out_scores, int dtok_packed, thr_stream_t stream) {
+    return launch_maxsim(qtok, n_queries, q_tokens, dtok, n_docs, d_tokens, tok_dim, cand, nullptr, 0,
+                         n_cand, out_scores, dtok_packed, stream);
+}
+
+extern "C" int thr_maxsim_ids(const uint16_t* qtok, int n_queries, int q_tokens, const uint16_t* dtok,
+                              int64_t n_docs, int d_tokens, int tok_dim, const int64_t* cand_ids,
+                              int64_t id_base, int n_cand, float* out_scores, int dtok_packed,
+                              thr_stream_t stream) {
+    THR_RETURN_IF(!cand_ids, THR_ERR_INVALID);
+    return launch_maxsim(qtok, n_queries, q_tokens, dtok, n_docs, d_tokens, tok_dim, nullptr, cand_ids,
+                         id_base, n_cand, out_scores, dtok_packed, stream);
 }

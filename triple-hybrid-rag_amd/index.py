@@ -254,10 +254,8 @@ class GpuIndex:
     def maxsim(self, qtok: torch.Tensor, cand_global_ids: torch.Tensor) -> torch.Tensor:
         """MaxSim of each query against its candidate docs (global ids; ids outside this
         shard or negative score -inf)."""
-        local = cand_global_ids - self.doc_base
-        local = torch.where((local >= 0) & (local < self.tokens.shape[0]) & (cand_global_ids >= 0),
-                            local, torch.full_like(local, -1)).to(torch.int32).contiguous()
-        return N.maxsim(self._t(qtok, torch.float16), self.tokens, local, packed=self.tokens_packed)
+        return N.maxsim_ids(self._t(qtok, torch.float16), self.tokens, self._t(cand_global_ids, torch.int64),
+                            self.doc_base, packed=self.tokens_packed)
 
     # ------------------------------------------------------------ pipeline
     def retrieve_batch(self, queries: torch.Tensor, query_terms: Optional[torch.Tensor] = None,
