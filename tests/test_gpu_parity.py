@@ -256,6 +256,28 @@ def test_bm25_matches_oracle(T):
     assert int(cnt[3]) == 0
 
 
+@pytest.mark.parametrize("knob", ["THR_DENSE_MFMA=32", "THR_DENSE_F16=q"])
+def test_dense_alternate_scan_builds_in_a_subprocess(knob):
+    """The documented A/B knobs of the default scan are read once per process:
+    THR_DENSE_MFMA=32 (the 32x32x16 build of the staggered kernel, with its own copy / query
+    image layouts) and THR_DENSE_F16=q (the two-blocks-per-CU kernel at dim <= 768).  The f16
+    parity tests run again under each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name, value = knob.split("=")
+    if os.environ.get(name) == value:
+        pytest.skip("already inside that run")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "test_dense_f16_shortlist_is_still_exact or test_dense_collection_filter_before_topk "
+                          "or test_dense_candidate_list_overflow_goes_to_rescue"],
+                         env=dict(os.environ, **{name: value}), cwd=root, capture_output=True, text=True,
+                         timeout=1200)
+    assert out.returncode == 0 and " passed" in out.stdout and "failed" not in out.stdout, \
+        out.stdout[-2000:] + out.stderr[-1000:]
+
+
 def test_bm25_small_block_shape_in_a_subprocess():
     """THR_BM25_SHAPE=small (256 threads / 4096 staged ids, four queries per CU) is read once per
     process: the two BM25 tests of this file run again under it."""
@@ -792,7 +814,7 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
         # holds the NORMALISED rows, NaN for rows without an embedding and for the tile padding
         img = idx.docs16.cpu().numpy()
         tiles = img.shape[0] // 32
-        if os.environ.get("THR_DENSE_MFMA") != "32" and d in (512, 768):
+        if os.environ.get("THR_DENSE_MFMA") != "32" and os.environ.get("THR_DENSE_F16") != "q" and d in (512, 768):
             # [tile][k32][row half ra][dim group g][r16][8]: the 16x16x32 MFMA's A fragments
             rows = (img.reshape(tiles, d // 32, 2, 4, 16, 8).transpose(0, 2, 4, 1, 3, 5)
                     .reshape(tiles * 32, d))
