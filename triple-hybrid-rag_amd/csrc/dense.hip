@@ -7,15 +7,21 @@
 // HNSW index inside PostgreSQL; this is the exact scan that index approximates.
 //
 // Pipeline per batch of queries (all kernels on one stream, no host sync):
-//   K1 dense_scan<MODE_ALL>     score a strided SAMPLE of doc groups for every query tile
-//   K2 kth_select               tau[q] = k'-th largest sample score (a lower bound on the
-//                               k'-th largest score over the whole corpus)
-//   K3 dense_scan<MODE_FILTER>  THE HBM-bound kernel: stream the corpus once per tile of QT
-//                               queries (queries LDS-resident), fp32 FMA, wave-transpose
-//                               reduction, append (score, doc) >= tau[q] to a candidate list
-//   K4 select_rescore           per query: shortlist k' by fp32 score, re-score in float64
-//                               with sequential accumulation (the oracle's contract), sort
-//                               (score desc, doc asc), certify with the fp32 error bound
+//   K0 pack_queries_f16         (default scan) queries -> fragment-major f16 register image
+//   K1 scan<MODE_ALL>           score a strided SAMPLE of row groups for every query tile
+//   K2 kth_select               tau[q] ~ the ks-th largest sample score: about `aim` rows of
+//                               the corpus will pass it
+//   K3 scan<MODE_FILTER>        THE dominant kernel: stream the corpus once per query tile,
+//                               emit (score, row) >= tau[q].  Default: dense_scan_f16qs (f16
+//                               MFMA over the normalised f16 copy, queries in registers);
+//                               dense_scan_f16 / dense_scan_mfma2 / the fp32 FMA scan are the
+//                               other flavours
+//   K4a select_band             per query: the band of candidates that can still reach the
+//                               top-k -> a shortlist of rows
+//   K4b rescore_rank            shortlist re-scored in float64 with sequential accumulation
+//                               (the oracle's contract), sorted (score desc, row asc),
+//                               certified with the scan's error bound
+//   K5 thr_dense_rescue         uncertified queries redone exhaustively
 // Algorithmic HBM bytes of K3 = n_docs * dim * 4 per tile pass.
 #include <stdlib.h>
 
@@ -388,7 +394,7 @@ __device__ uint32_t block_radix_select(KeyFn keyfn, int n, int kk, int* hist, in
 }
 
 // Same select over items each thread enumerates itself: keyfn(u), u in [0, my_n) (the
-// candidate lists of select_rescore: a thread's items are my_ptr[u * my_stride]).
+// candidate lists of select_band: a thread's items are my_ptr[u * my_stride]).
 template <typename KeyFn>
 __device__ uint32_t block_radix_select_local(KeyFn keyfn, int my_n, int kk, int* hist, int* bc) {
     uint32_t prefix = 0, mask = 0;
@@ -652,7 +658,10 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
     return s;
 }
 
-// K4: shortlist, float64 rescoring, ordering, certificate.  One block (4 waves) per query.
+// K4: shortlist (select_band), then float64 rescoring, ordering, certificate (rescore_rank).
+// One block (4 waves) per query in each.  They were one kernel until the counters showed its two
+// halves wanting different things: the selection is a chain of dependent memory round trips that
+// only occupancy hides, the rescoring is float64-ALU and LDS bound and heavy on registers.
 //
 //  band    the candidates that can still reach the top-k: with a_k the k-th largest scan score,
 //          k rows have true cosine >= a_k/||q|| - eps, so a row whose scan score is below
@@ -661,47 +670,37 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
 //          candidates per thread stay in registers across the passes.
 //  rescore float64 SEQUENTIAL sums (the oracle's contract), one lane per row, rows dealt
 //          round-robin to the 4 waves.  Each wave stages its rows through its own LDS tile, 32
-//          dims at a time, with coalesced loads (8 lanes per 128-byte line) and the next chunk
+//          dims at a time, with coalesced loads (8 lanes per 128-byte line) and the next chunks
 //          already in flight in registers -- no block barrier inside the loop, the waves run
 //          free.  Lane 63 of wave 3 accumulates ||q||^2 in the same instruction stream.
-//  order   rank sort of the <= 256 rescored rows under (score desc, id asc).
+//  order   rank sort of the rescored rows under (score desc, id asc).
 constexpr int SEL_THREADS = 256;
-constexpr int RS_ROWS = 32;        // rows per wave per batch
 constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
 constexpr int SEL_REG = 16;        // candidates per thread kept in registers (4096 per query; the scan aims at ~2900)
-constexpr int RS_DEPTH = 4;        // 32-dim chunks of a row in flight per wave (dim / 32 is a multiple)
+constexpr int RS_DEPTH = 2;        // 32-dim chunks of a row in flight per wave (dim / 32 is a multiple)
 constexpr int SEL_BIG_BAND = 1024; // band capacity of the second-chance launch
 constexpr int SEL_FLAT = 8192;     // candidates of the per-lane segments addressed through a flat LDS index
-static size_t select_lds_bytes(int dim) {
-    const size_t stage = sizeof(float4) * 4 * RS_ROWS * RS_STRIDE, hist = sizeof(int) * CS_BINS;
-    return sizeof(float) * dim + (stage > hist ? stage : hist);
-}
-// CAPB = rows the band may hold: 256 in the first launch; the queries it could not certify because
-// the band did not fit (score distributions squeezed into a narrow range: anisotropic embeddings
-// put hundreds of rows within the f16 error band of the k-th) get a second launch with 1024
-// (redo_flags != nullptr: workgroups of certified or overflowed queries exit at once) before the
-// exhaustive path is asked.
-template <int CAPB>
-__global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
-    const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
-    const float* __restrict__ queries, const float* __restrict__ tau,
+static size_t band_lds_bytes(int dim) { return sizeof(float) * dim + sizeof(int) * CS_BINS; }
+// K4a: the shortlist of one query -- which candidate rows get a float64 score.  Light on
+// registers and LDS (four workgroups per CU): its phases are chains of dependent memory round
+// trips (segment counts -> candidates -> histogram -> band), which only occupancy hides.
+// Writes sel_rows[q][0..ns), sel_meta[q] = {ns, floor (float bits), overflow}.
+constexpr int CAPB = SEL_BIG_BAND;   // rows the band may hold
+__global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
+    int dim, const float* __restrict__ queries, const float* __restrict__ tau,
     const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
     const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
-    double doc_relerr, const float* __restrict__ qerr, double* __restrict__ out_scores,
-    int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts,
-    uint32_t* __restrict__ out_flags, const uint32_t* __restrict__ redo_flags, int nseg,
-    int seg_cap, const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll) {
-    if (redo_flags && (redo_flags[blockIdx.x] & (THR_FLAG_CERTIFIED | THR_FLAG_OVERFLOW))) return;
-    extern __shared__ float4 lds_sel[];  // [dim/4] query | hist (band) / 4 wave stage tiles (rescore)
+    double doc_relerr, const float* __restrict__ qerr, int nseg, int seg_cap,
+    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
+    int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_meta) {
+    extern __shared__ float4 lds_sel[];  // [dim/4] query | hist
     __shared__ int aux[8];
     __shared__ int bc[4];
-    __shared__ double s_s[CAPB], o_s[CAPB];
-    __shared__ int64_t s_id[CAPB], o_id[CAPB];
+    __shared__ int32_t s_id[CAPB];
     __shared__ int n_sel;
-    __shared__ double s_qn, wsum[4];
+    __shared__ double wsum[4];
     float* lds_qv = reinterpret_cast<float*>(lds_sel);
     int* hist = reinterpret_cast<int*>(lds_sel + dim / 4);
-    float4* stage_all = lds_sel + dim / 4;
 
     const int q = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -816,10 +815,6 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     }
     for (int i = threadIdx.x; i < dim / 4; i += SEL_THREADS)
         lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
-    for (int i = threadIdx.x; i < CAPB; i += SEL_THREADS) {
-        s_s[i] = o_s[i] = -INFINITY;
-        s_id[i] = o_id[i] = INT64_MAX;
-    }
     if (threadIdx.x == 0) n_sel = 0;
     __syncthreads();
 
@@ -965,39 +960,87 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
             }
         }
     }
-    __syncthreads();  // also: every wave is done with hist before the stage tiles reuse it
+    __syncthreads();
     const int ns = n_sel;
+    for (int i = threadIdx.x; i < ns; i += SEL_THREADS) sel_rows[(int64_t)q * CAPB + i] = s_id[i];
+    if (threadIdx.x == 0) {
+        sel_meta[4 * q + 0] = ns;
+        sel_meta[4 * q + 1] = (int32_t)__float_as_uint(floor32);
+        sel_meta[4 * q + 2] = overflow ? 1 : 0;
+    }
+}
 
-    // ---- float64 rescoring ----
+// K4b: float64 scores of the shortlist, rank sort, certificate.  NB = the rows it can take: the
+// first launch (256) serves every query whose shortlist fits, the second (1024) the few whose
+// band was wider (score distributions squeezed into a narrow range: anisotropic embeddings put
+// hundreds of rows within the f16 error band of the k-th); each exits at once on the others.
+//
+// Two waves per query, 64 rows per wave (every lane holds a row).  What bounds it is the gather:
+// 2048 queries x ~105 rows x 3 KB = 645 MB read as scattered 128-byte lines, 4.3 TB/s at 150 us --
+// four waves of 32 rows, two of 64, two or four chunks in flight, three to six workgroups per CU
+// all land within 5 % of each other.  The query is one more row of the shortlist: its dot
+// product with itself, in the same sequential order, is ||q||^2.
+constexpr int RR_WAVES = 2, RR_THREADS = 64 * RR_WAVES, RR_ROWS = 64;
+static size_t rescore_lds_bytes(int dim) {
+    return sizeof(float) * dim + sizeof(float4) * RR_WAVES * RR_ROWS * RS_STRIDE;
+}
+template <int NB>
+__global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
+    const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
+    const float* __restrict__ queries, int k, double eps32, double doc_relerr,
+    const float* __restrict__ qerr, const int32_t* __restrict__ sel_rows,
+    const int32_t* __restrict__ sel_meta, double* __restrict__ out_scores,
+    int64_t* __restrict__ out_ids, int32_t* __restrict__ out_counts, uint32_t* __restrict__ out_flags) {
+    const int q = blockIdx.x;
+    const int ns = sel_meta[4 * q + 0];
+    if (NB == THR_DENSE_MAX_K ? ns > THR_DENSE_MAX_K : ns <= THR_DENSE_MAX_K) return;
+    const float floor32 = __uint_as_float((uint32_t)sel_meta[4 * q + 1]);
+    const bool overflow = sel_meta[4 * q + 2] != 0;
+    extern __shared__ float4 lds_sel[];  // [dim/4] query | RR_WAVES stage tiles
+    __shared__ double s_s[NB], o_s[NB];
+    __shared__ int64_t s_id[NB], o_id[NB];
+    __shared__ double s_qn;
+    __shared__ int n_valid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double eq = qerr ? (double)qerr[q] : 0.0;
+    const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
+    for (int i = threadIdx.x; i < dim / 4; i += RR_THREADS)
+        lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
+    for (int i = threadIdx.x; i < NB; i += RR_THREADS) {
+        s_s[i] = o_s[i] = -INFINITY;
+        s_id[i] = i < ns ? (int64_t)sel_rows[(int64_t)q * SEL_BIG_BAND + i] : INT64_MAX;
+        o_id[i] = INT64_MAX;
+    }
+    if (threadIdx.x == 0) n_valid = 0;
+    __syncthreads();
+
+    // ---- float64 rescoring: SEQUENTIAL sums (the oracle's contract), one lane per row ----
     // (native vectors, not HIP's float4 class: see dense_scan_mfma2 -- a float4 array that is
     // copied into LDS is demoted to scratch memory)
-    f32x4* stage = reinterpret_cast<f32x4*>(stage_all) + wave * (RS_ROWS * RS_STRIDE);
+    f32x4* stage = reinterpret_cast<f32x4*>(lds_sel + dim / 4) + wave * (RR_ROWS * RS_STRIDE);
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
     const f32x4* qv4 = reinterpret_cast<const f32x4*>(lds_sel);
     const int lrow = lane >> 3, lch = lane & 7;
-    const bool q_lane = wave == 3 && lane == 63;  // accumulates ||q||^2 instead of a row
     const int cpr = dim / 4, nchunk = dim / 32;
-    double qq = 0.0;
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(queries + (int64_t)q * dim);
     // (the row norm of this thread's first shortlist slot: requested now, used after the loop)
     const double dn_first = (int)threadIdx.x < ns ? dnorm[s_id[threadIdx.x]] : 0.0;
-    for (int b0 = 0; b0 < ns || (b0 == 0 && q_lane); b0 += 4 * RS_ROWS) {
-        // shortlist slot of (wave, staged row r) is b0 + wave + 4 r; loader rows lrow + 8 u
-        int64_t off[4];
+    for (int b0 = 0; b0 <= ns; b0 += RR_WAVES * RR_ROWS) {
+        // slot of (wave, staged row r) is b0 + wave + RR_WAVES r; slot ns is the query itself;
+        // a lane loads 16 bytes of rows lrow + 8 u (8 lanes per 128-byte line)
+        const f32x4* rp[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int j = b0 + wave + 4 * (lrow + 8 * u);
-            j = j < ns ? j : (ns > 0 ? ns - 1 : 0);
-            off[u] = (ns > 0 ? s_id[j] : 0) * cpr + lch;
+        for (int u = 0; u < 8; ++u) {
+            int j = b0 + wave + RR_WAVES * (lrow + 8 * u);
+            j = j < ns ? j : ns;
+            rp[u] = (j < ns ? docs4 + s_id[j] * cpr : q4) + lch;
         }
-        const int jm = b0 + wave + 4 * lane;  // this lane's own row (lanes 0..31)
-        const bool has_row = lane < RS_ROWS && jm < ns;
-        // RS_DEPTH chunks of every row in flight per wave (registers): the loop is bound by the
-        // latency of these gathers, not by the float64 chain
-        f32x4 nxt[RS_DEPTH][4];
+        const int jm = b0 + wave + RR_WAVES * lane;  // this lane's own slot
+        f32x4 nxt[RS_DEPTH][8];
 #pragma unroll
         for (int dd = 0; dd < RS_DEPTH; ++dd)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[dd][u] = docs4[off[u] + 8 * dd];   // (nchunk >= RS_DEPTH)
+            for (int u = 0; u < 8; ++u) nxt[dd][u] = rp[u][8 * dd];   // (nchunk >= RS_DEPTH)
         double dot = 0.0;
 #pragma unroll 1
         for (int ck0 = 0; ck0 < nchunk; ck0 += RS_DEPTH) {
@@ -1005,34 +1048,32 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
             for (int dd = 0; dd < RS_DEPTH; ++dd) {
                 const int ck = ck0 + dd;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[dd][u];
+                for (int u = 0; u < 8; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[dd][u];
                 // (the last trips re-request the last chunk)
                 const int cn = ck + RS_DEPTH < nchunk ? ck + RS_DEPTH : nchunk - 1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) nxt[dd][u] = docs4[off[u] + 8 * cn];
+                for (int u = 0; u < 8; ++u) nxt[dd][u] = rp[u][8 * cn];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const f32x4* src = q_lane ? qv4 + 8 * ck : stage + (lane & (RS_ROWS - 1)) * RS_STRIDE;
+                const f32x4* src = stage + lane * RS_STRIDE;
                 const f32x4* qv = qv4 + 8 * ck;
-                double acc = q_lane ? qq : dot;
 #pragma unroll
                 for (int ch = 0; ch < 8; ++ch) {
                     const f32x4 x = src[ch], y = qv[ch];
-                    acc = __dadd_rn(acc, __dmul_rn((double)x.x, (double)y.x));
-                    acc = __dadd_rn(acc, __dmul_rn((double)x.y, (double)y.y));
-                    acc = __dadd_rn(acc, __dmul_rn((double)x.z, (double)y.z));
-                    acc = __dadd_rn(acc, __dmul_rn((double)x.w, (double)y.w));
+                    dot = __dadd_rn(dot, __dmul_rn((double)x.x, (double)y.x));
+                    dot = __dadd_rn(dot, __dmul_rn((double)x.y, (double)y.y));
+                    dot = __dadd_rn(dot, __dmul_rn((double)x.z, (double)y.z));
+                    dot = __dadd_rn(dot, __dmul_rn((double)x.w, (double)y.w));
                 }
-                if (q_lane) qq = acc; else dot = acc;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (q_lane && b0 == 0) s_qn = __dsqrt_rn(qq);
-        if (has_row) s_s[jm] = dot;  // the raw dot product for now
+        if (jm < ns) s_s[jm] = dot;               // the raw dot product for now
+        else if (jm == ns) s_qn = __dsqrt_rn(dot);  // ||q||
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < ns; p += SEL_THREADS) {
+    for (int p = threadIdx.x; p < ns; p += RR_THREADS) {
         const int64_t row = s_id[p];
         const double qn = s_qn, dn = p == (int)threadIdx.x ? dn_first : dnorm[row], dot = s_s[p];
         double sim = -INFINITY;
@@ -1043,7 +1084,7 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     __syncthreads();
     // rank sort: ids are distinct, so (score desc, id asc) is a strict order on the valid rows;
     // rows without an embedding all carry (-inf, INT64_MAX), which is what o_s/o_id hold already
-    for (int p = threadIdx.x; p < ns; p += SEL_THREADS) {
+    for (int p = threadIdx.x; p < ns; p += RR_THREADS) {
         const double ms = s_s[p];
         const int64_t mi = s_id[p];
         if (mi == INT64_MAX) continue;
@@ -1055,13 +1096,17 @@ __global__ __launch_bounds__(SEL_THREADS, 3) void select_rescore(
     __syncthreads();
 
     // results + certificate
-    const int valid = __syncthreads_count(threadIdx.x < k && o_s[threadIdx.x] > -INFINITY);
-    for (int i = threadIdx.x; i < k; i += SEL_THREADS) {
+    int mine_valid = 0;
+    for (int i = threadIdx.x; i < k; i += RR_THREADS) {
         const bool ok = o_s[i] > -INFINITY;
+        mine_valid += ok ? 1 : 0;
         out_scores[(int64_t)q * k + i] = ok ? o_s[i] : -INFINITY;
         out_ids[(int64_t)q * k + i] = ok ? o_id[i] : -1;
     }
+    if (mine_valid) atomicAdd(&n_valid, mine_valid);
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const int valid = n_valid;
         uint32_t flag = overflow ? THR_FLAG_OVERFLOW : 0u;
         bool cert;
         if (overflow) {
@@ -1278,6 +1323,7 @@ struct DensePlan {
                   // candidate area is written in per-lane segments
     int64_t groups;
     int64_t sample_groups, sample_stride, sample_docs;
+    size_t off_selrows, off_selmeta;
     bool sampled;
     int tile_cap;
     size_t off_tau, off_qerr, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, off_qfrag, total;
@@ -1408,6 +1454,8 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     p.off_tlist = take(sizeof(Cand) * (size_t)p.ntiles * p.tile_cap);
     p.off_sample = take(sizeof(float) * (size_t)p.qpad * (size_t)p.sample_docs);
     p.off_qfrag = take(p.qreg ? sizeof(_Float16) * (size_t)p.qpad * (size_t)dim : 0);
+    p.off_selrows = take(sizeof(int32_t) * (size_t)p.qpad * SEL_BIG_BAND);   // K4a -> K4b shortlists
+    p.off_selmeta = take(sizeof(int32_t) * 4 * (size_t)p.qpad);
     p.total = off;
     return p;
 }
@@ -1772,18 +1820,20 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
     }
     const double u = 5.9604644775390625e-08;
     const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
-    hipLaunchKernelGGL(select_rescore<THR_DENSE_MAX_K>, dim3(n_queries), dim3(SEL_THREADS),
-                       select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
-                       tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
-                       out_ids, out_counts, out_flags, (const uint32_t*)nullptr, nseg,
-                       nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll);
+    int32_t* sel_rows = (int32_t*)(ws + p.off_selrows);
+    int32_t* sel_meta = (int32_t*)(ws + p.off_selmeta);
+    hipLaunchKernelGGL(select_band, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st, dim,
+                       queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr,
+                       qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll, sel_rows, sel_meta);
     if ((rc = launch_status())) return rc;
-    // second chance with a 1024-row band for the queries whose band did not fit 256 rows
-    hipLaunchKernelGGL(select_rescore<SEL_BIG_BAND>, dim3(n_queries), dim3(SEL_THREADS),
-                       select_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, tau, cnt, cand,
-                       tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr, qerr, out_scores,
-                       out_ids, out_counts, out_flags, (const uint32_t*)out_flags, nseg,
-                       nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll);
+    hipLaunchKernelGGL(rescore_rank<THR_DENSE_MAX_K>, dim3(n_queries), dim3(RR_THREADS),
+                       rescore_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, k, eps32,
+                       doc_relerr, qerr, sel_rows, sel_meta, out_scores, out_ids, out_counts, out_flags);
+    if ((rc = launch_status())) return rc;
+    // the queries whose band did not fit 256 rows
+    hipLaunchKernelGGL(rescore_rank<SEL_BIG_BAND>, dim3(n_queries), dim3(RR_THREADS),
+                       rescore_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, k, eps32,
+                       doc_relerr, qerr, sel_rows, sel_meta, out_scores, out_ids, out_counts, out_flags);
     return launch_status();
 }
 
