@@ -678,6 +678,73 @@ def test_triple_hybrid_pipeline_fused_top10(T):
             assert [f100[j] for j in order] == list(ids3[i])
 
 
+def test_index_build_rows_through_the_kernels(T, tmp_path):
+    """reference-shaped table rows (rag_child_chunks / rag_parent_chunks / rag_entities /
+    rag_relations / rag_entity_mentions) -> index_build.from_rows -> save / load -> to_gpu(), and
+    every channel of the resulting GpuIndex equals the oracle run on the HostIndex arrays; the
+    drop-in RPC client answers from the same index with the store's ids and texts."""
+    from triple_hybrid_rag_amd import index_build as IB
+    from triple_hybrid_rag_amd.backend import GpuIndexClient
+    rng = np.random.default_rng(41)
+    n, d, n_ent = 4000, 768, 300
+    words = [f"w{i}" for i in range(400)]
+    zipf = 1.0 / np.arange(1, 401)
+    zipf /= zipf.sum()
+    emb = rng.standard_normal((n, d)).astype(np.float32)
+    children = []
+    for i in range(n):
+        toks = rng.choice(400, size=int(rng.integers(3, 40)), p=zipf)
+        children.append({"id": f"c{i}", "parent_id": f"p{i // 4}", "document_id": f"d{i // 50}",
+                         "text": " ".join(words[t] for t in toks), "page": 1 + i % 7,
+                         "modality": "table" if i % 13 == 0 else "text",
+                         "collection": f"col{i % 5}",
+                         "embedding_1024": None if i % 97 == 0 else emb[i].tolist()})
+    parents = [{"id": f"p{j}", "text": f"parent text {j}", "section_heading": f"S{j % 9}"}
+               for j in range(n // 4)]
+    ents = [{"id": f"e{j}", "name": f"entity{j}"} for j in range(n_ent)]
+    rels = [{"subject_entity_id": f"e{int(a)}", "object_entity_id": f"e{int(b)}"}
+            for a, b in rng.integers(0, n_ent, size=(900, 2))]
+    mens = [{"entity_id": f"e{int(e)}", "child_chunk_id": f"c{int(c)}", "confidence": float(cf)}
+            for e, c, cf in zip(rng.integers(0, n_ent, 2500), rng.integers(0, n, 2500),
+                                rng.uniform(0.2, 1.0, 2500).astype(np.float32))]
+    hi = IB.from_rows(children, parents, ents, rels, mens)
+    IB.save(hi, str(tmp_path / "idx"))
+    hi = IB.load(str(tmp_path / "idx"))
+    idx = hi.to_gpu()
+    x = np.asarray(hi.docs)
+    assert idx.shortlist == "f16" and not x[97].any()
+    nq = 24
+    q = (x[rng.integers(1, n, nq)] + 0.7 * rng.standard_normal((nq, d))).astype(np.float32)
+    vocab = hi.store.vocab
+    qt = np.array([[vocab[words[int(t)]] for t in rng.choice(400, size=3, p=zipf)] for _ in range(nq)],
+                  dtype=np.int32)
+    seeds = rng.integers(0, n_ent, size=(nq, 2)).astype(np.int32)
+    res = idx.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    _, Id, _ = CO.dense_topk_exact(x, q, 100)
+    _, Il = O.bm25_topk(hi.rowptr, hi.post_doc, hi.post_tf, hi.doclen, hi.idf, hi.avgdl, qt, n, 50)
+    _, Ig = O.graph_topk(hi.ent_rowptr, hi.ent_col, hi.men_rowptr, hi.men_chunk, hi.men_conf, seeds, 2, n, 50)
+    ids, sc, cnt = res.ids.cpu().numpy(), res.scores.cpu().numpy(), res.counts.cpu().numpy()
+    for i in range(nq):
+        assert 97 not in Id[i]                      # the row without an embedding never ranks
+        ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 10)
+        assert list(ids[i, :cnt[i]]) == ei and list(sc[i, :cnt[i]]) == es, i
+    # the Supabase-shaped client over the same index: ids, texts and the collection filter
+    client = GpuIndexClient(idx, hi.store, org_id="org", lexical_and=True)
+    rows = client.rpc("rag2_semantic_search", {"p_org_id": "org", "p_embedding": q[0].tolist(),
+                                               "p_limit": 20, "p_collection": "col2"}).execute().data
+    s = O.cosine_scores_f64(x, q[0])
+    s[np.array([c["collection"] != "col2" for c in children])] = -np.inf
+    _, ti = O.topk_desc(s, 20)
+    assert [r["child_id"] for r in rows] == [f"c{int(j)}" for j in ti]
+    assert all(r["text"] == children[int(r["child_id"][1:])]["text"] for r in rows)
+    rows = client.rpc("rag2_lexical_search", {"p_org_id": "org", "p_query": f"{words[3]} {words[11]}",
+                                              "p_limit": 15}).execute().data
+    _, Il2 = O.bm25_topk(hi.rowptr, hi.post_doc, hi.post_tf, hi.doclen, hi.idf, hi.avgdl,
+                         np.array([[vocab[words[3]], vocab[words[11]]]], dtype=np.int32), n, 15,
+                         conjunctive=True)
+    assert [r["child_id"] for r in rows] == [f"c{int(j)}" for j in Il2[0]]
+
+
 def test_full_size_1m_dense(T):
     """BASELINE config 1 (1M x 768, top-10 of top-100): exact check of 8 queries against the
     C oracle + size-independent properties on the whole batch."""

@@ -22,6 +22,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -63,7 +65,12 @@ class GpuIndex:
     def _t(self, a, dtype):
         if isinstance(a, torch.Tensor):
             return a.to(device=self.device, dtype=dtype).contiguous()
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:   # a memory-mapped index (index_build.load): read-only is fine,
+            with warnings.catch_warnings():   # the tensor is only the source of the device copy
+                warnings.simplefilter("ignore", UserWarning)
+                return torch.from_numpy(a).to(device=self.device, dtype=dtype)
+        return torch.from_numpy(a).to(device=self.device, dtype=dtype)
 
     SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
     F16_DIMS = (512, 768, 1024)
