@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where the float16-copy scan spends its time: per-phase s_memtime sums of every wave
-(thr_dense_scan_stamps_f16), at the bench shape.  python3 scripts/scan_stamps.py [queries] [docs]"""
+(thr_dense_scan_stamps_f16), at the bench shape.  Only the 4-wave-block kernel dense_scan_f16q has a
+stamped build: run with THR_DENSE_F16=q at dim <= 768 (the default staggered kernel answers
+"unsupported shape").  THR_DENSE_F16=q python3 scripts/scan_stamps.py [queries] [docs]"""
 import json
 import os
 import sys
