@@ -58,19 +58,19 @@ __device__ __forceinline__ bool gr_insert(uint32_t* keys, uint8_t* dist, uint32_
     return false;
 }
 
-// block-wide bitonic sort of uint64 keys, ascending, n = power of two
+// block-wide bitonic sort of uint64 keys, ascending, n = power of two.  Thread t takes PAIR t of a
+// stage (i = t with a zero bit inserted at j, partner i | j): every thread of every trip does a
+// compare-exchange (the i ^ j form leaves half of them idle).
 __device__ inline void sort_u64_asc(uint64_t* a, int n) {
     for (int k = 2; k <= n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                int p = i ^ j;
-                if (p > i) {
-                    bool up = (i & k) == 0;
-                    uint64_t x = a[i], y = a[p];
-                    if (up ? (x > y) : (x < y)) {
-                        a[i] = y;
-                        a[p] = x;
-                    }
+            for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t x = a[i], y = a[p];
+                if (up ? (x > y) : (x < y)) {
+                    a[i] = y;
+                    a[p] = x;
                 }
             }
             __syncthreads();

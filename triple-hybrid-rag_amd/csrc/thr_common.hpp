@@ -55,17 +55,16 @@ template <int N>
 __device__ void bitonic_sort_desc(double* s, int64_t* id) {
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < N; i += blockDim.x) {
-                int p = i ^ j;
-                if (p > i) {
-                    bool up = (i & k) == 0;  // this run sorted best-first
-                    double sa = s[i], sb = s[p];
-                    int64_t ia = id[i], ib = id[p];
-                    bool swap = up ? better(sb, ib, sa, ia) : better(sa, ia, sb, ib);
-                    if (swap) {
-                        s[i] = sb; s[p] = sa;
-                        id[i] = ib; id[p] = ia;
-                    }
+            // thread t takes pair t of the stage: i = t with a zero bit inserted at j, partner i | j
+            for (int t = threadIdx.x; t < N / 2; t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                bool up = (i & k) == 0;  // this run sorted best-first
+                double sa = s[i], sb = s[p];
+                int64_t ia = id[i], ib = id[p];
+                bool swap = up ? better(sb, ib, sa, ia) : better(sa, ia, sb, ib);
+                if (swap) {
+                    s[i] = sb; s[p] = sa;
+                    id[i] = ib; id[p] = ia;
                 }
             }
             __syncthreads();
@@ -77,17 +76,15 @@ __device__ void bitonic_sort_desc(double* s, int64_t* id) {
 __device__ inline void bitonic_sort_desc_n(double* s, int64_t* id, int n) {
     for (int k = 2; k <= n; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                int p = i ^ j;
-                if (p > i) {
-                    bool up = (i & k) == 0;
-                    double sa = s[i], sb = s[p];
-                    int64_t ia = id[i], ib = id[p];
-                    bool swap = up ? better(sb, ib, sa, ia) : better(sa, ia, sb, ib);
-                    if (swap) {
-                        s[i] = sb; s[p] = sa;
-                        id[i] = ib; id[p] = ia;
-                    }
+            for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                bool up = (i & k) == 0;
+                double sa = s[i], sb = s[p];
+                int64_t ia = id[i], ib = id[p];
+                bool swap = up ? better(sb, ib, sa, ia) : better(sa, ia, sb, ib);
+                if (swap) {
+                    s[i] = sb; s[p] = sa;
+                    id[i] = ib; id[p] = ia;
                 }
             }
             __syncthreads();
