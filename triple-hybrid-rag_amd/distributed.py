@@ -122,17 +122,19 @@ class ShardedIndex:
         w.update(weights or {})
         L = self.local
         ch = {}
+        # the lexical and graph kernels run on a side stream beside the dense channel; the
+        # exchanges stay on the main stream, after the join
+        lex, gra, join = L.side_channels(query_terms, lexical_top_k, query_seeds, graph_top_k, hops)
         Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False)
         Ss, Is = self._merge(Ss, Is, semantic_top_k)
         ch["semantic"] = (Ss, Is, None)
+        join()
         Il = Ig = None
-        if query_terms is not None and L.lex is not None:
-            Sl, Il, _ = L.bm25_search(query_terms, lexical_top_k)
-            Sl, Il = self._merge(Sl, Il, lexical_top_k)
+        if lex is not None:
+            Sl, Il = self._merge(lex[0], lex[1], lexical_top_k)
             ch["lexical"] = (Sl, Il, None)
-        if query_seeds is not None and L.graph is not None:
-            Sg, Ig, _ = L.graph_search(query_seeds, graph_top_k, hops)
-            Sg, Ig = self._merge(Sg, Ig, graph_top_k)
+        if gra is not None:
+            Sg, Ig = self._merge(gra[0], gra[1], graph_top_k)
             ch["graph"] = (Sg, Ig, None)
         rerank = qtok is not None and L.tokens is not None
         n_fused = max(rerank_top_k, top_k) if rerank else top_k

@@ -22,6 +22,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
+import os
 import warnings
 
 import numpy as np
@@ -265,6 +266,41 @@ class GpuIndex:
                             self.doc_base, packed=self.tokens_packed)
 
     # ------------------------------------------------------------ pipeline
+    def side_channels(self, query_terms, lexical_top_k: int, query_seeds, graph_top_k: int, hops: int):
+        """The lexical and graph channels of a batch on a second HIP stream, so that they run
+        beside the dense channel instead of after it: they do not depend on it before the fusion,
+        they are latency-bound (one workgroup per query, a few per CU), and the dense pipeline has
+        stretches that leave CUs idle (sample pass, shortlist, the gather-bound rescoring, the
+        tail of the scan).  Returns (lexical result or None, graph result or None, join): call
+        ``join()`` on the main stream before the results are read there.  THR_SIDE_STREAM=0 keeps
+        everything on one stream."""
+        want_lex = query_terms is not None and self.lex is not None
+        want_gra = query_seeds is not None and self.graph is not None
+        if not (want_lex or want_gra):
+            return None, None, (lambda: None)
+        if os.environ.get("THR_SIDE_STREAM") == "0" or self.device.type != "cuda":
+            lex = self.bm25_search(query_terms, lexical_top_k) if want_lex else None
+            gra = self.graph_search(query_seeds, graph_top_k, hops) if want_gra else None
+            return lex, gra, (lambda: None)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)            # the inputs were produced on the main stream
+        for t in (query_terms, query_seeds):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            lex = self.bm25_search(query_terms, lexical_top_k) if want_lex else None
+            gra = self.graph_search(query_seeds, graph_top_k, hops) if want_gra else None
+        for res in (lex, gra):
+            if res is not None:
+                for t in res:
+                    t.record_stream(main)       # allocated on the side stream, read on the main one
+
+        def join():
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        return lex, gra, join
+
     def retrieve_batch(self, queries: torch.Tensor, query_terms: Optional[torch.Tensor] = None,
                        query_seeds: Optional[torch.Tensor] = None, top_k: int = 10,
                        semantic_top_k: int = 100, lexical_top_k: int = 50, graph_top_k: int = 50,
@@ -276,15 +312,17 @@ class GpuIndex:
         w = {"lexical": 0.7, "semantic": 0.8, "graph": 1.0}
         w.update(weights or {})
         ch = {}
+        lex, gra, join = self.side_channels(query_terms, lexical_top_k, query_seeds, graph_top_k, hops)
         Ss, Is, Cs, nres = self.dense_search(queries, semantic_top_k, rescue=rescue, sync=False)
         ch["semantic"] = (Ss, Is, Cs)
+        join()
         Il = Ig = None
-        if query_terms is not None and self.lex is not None:
-            Sl, Il, Cl = self.bm25_search(query_terms, lexical_top_k)
-            ch["lexical"] = (Sl, Il, Cl)
-        if query_seeds is not None and self.graph is not None:
-            Sg, Ig, Cg = self.graph_search(query_seeds, graph_top_k, hops)
-            ch["graph"] = (Sg, Ig, Cg)
+        if lex is not None:
+            ch["lexical"] = lex
+            Il = lex[1]
+        if gra is not None:
+            ch["graph"] = gra
+            Ig = gra[1]
         rerank = qtok is not None and self.tokens is not None
         n_fused = max(rerank_top_k, top_k) if rerank else top_k
         ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, n_fused, w["lexical"], w["semantic"], w["graph"])
