@@ -283,7 +283,11 @@ class GpuIndex:
             gra = self.graph_search(query_seeds, graph_top_k, hops) if want_gra else None
             return lex, gra, (lambda: None)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # a high-priority queue: its short kernels get their CUs first and are gone before
+            # the scan's one-workgroup-per-CU launch needs them (triple + rerank step 4.57 ms on
+            # one stream, 4.42 with an equal-priority side stream -- THR_SIDE_STREAM=eq --, 4.32 so)
+            eq = os.environ.get("THR_SIDE_STREAM") == "eq"
+            self._side = torch.cuda.Stream(device=self.device, priority=0 if eq else -1)
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)            # the inputs were produced on the main stream
         for t in (query_terms, query_seeds):
