@@ -978,7 +978,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
 // Two waves per query, 64 rows per wave (every lane holds a row).  What bounds it is the gather:
 // 2048 queries x ~105 rows x 3 KB = 645 MB read as scattered 128-byte lines, 4.3 TB/s at 150 us --
 // four waves of 32 rows, two of 64, two or four chunks in flight, three to six workgroups per CU
-// all land within 5 % of each other.  The query is one more row of the shortlist: its dot
+// all land within 5 % of each other; 256-byte steps per row (half the occupancy) are 17 % slower.  The query is one more row of the shortlist: its dot
 // product with itself, in the same sequential order, is ||q||^2.
 constexpr int RR_WAVES = 2, RR_THREADS = 64 * RR_WAVES, RR_ROWS = 64;
 static size_t rescore_lds_bytes(int dim) {
