@@ -128,9 +128,9 @@ int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int
  *   docs16 != NULL: the scan streams a float16 COPY written by thr_dense_quantize_f16: an opaque
  *                   FRAGMENT-MAJOR image of thr_dense_f16_copy_bytes(n_docs, dim) bytes,
  *                   [row tile of 32][dims 32 k .. +32][rows 16 a .. +16][lane = r + 16 g][8 halves]
- *                   = the register image of the v_mfma_f32_16x16x32_f16 row operand at dim 512 /
- *                   768 (THR_DENSE_MFMA=32 in the environment of BOTH the quantiser and the scan,
- *                   and always at dim 1024: [row tile of 32][k-step of 16 dims][lane = r + 32 h]
+ *                   = the register image of the v_mfma_f32_16x16x32_f16 row operand
+ *                   (THR_DENSE_MFMA=32 in the environment of BOTH the quantiser and the scan:
+ *                   [row tile of 32][k-step of 16 dims][lane = r + 32 h]
  *                   [8 halves], v_mfma_f32_32x32x16_f16), holding the NORMALISED rows
  *                   d/||d|| (NaN for rows without an embedding and for the padding of the last
  *                   tile; doc_rel_err = max_d ||fp16(d/||d||) - d/||d|| ||, any value range).

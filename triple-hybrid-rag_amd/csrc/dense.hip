@@ -1392,7 +1392,8 @@ static int qreg_shape(int dim) {
         const char* e = getenv("THR_DENSE_MFMA");
         v = (e && atoi(e) == 32) ? 32 : 16;
     }
-    return qreg_staggered(dim) ? v : 32;
+    (void)dim;   // (both register-resident kernels take either shape)
+    return v;
 }
 constexpr int QREG_MAX_SEG = 1024;
 
@@ -1687,9 +1688,9 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
         return launch_status();
     }
 #undef THR_QS_LAUNCH
-#define THR_Q_LAUNCH(DIM)                                                                         \
+#define THR_Q_LAUNCH(DIM, SHAPE)                                                                  \
     {                                                                                             \
-        auto kern = dense_scan_f16q<DIM, MODE, PROF>;                                             \
+        auto kern = dense_scan_f16q<DIM, MODE, PROF, SHAPE>;                                      \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                            QScan<DIM>::LDS_BYTES);                                \
@@ -1700,9 +1701,9 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
                            doc_coll, query_coll, n_queries, stamps);                              \
     }
     switch (dim) {
-        case 512: THR_Q_LAUNCH(512) break;
-        case 768: THR_Q_LAUNCH(768) break;
-        case 1024: THR_Q_LAUNCH(1024) break;
+        case 512: if (shape == 16) THR_Q_LAUNCH(512, 16) else THR_Q_LAUNCH(512, 32) break;
+        case 768: if (shape == 16) THR_Q_LAUNCH(768, 16) else THR_Q_LAUNCH(768, 32) break;
+        case 1024: if (shape == 16) THR_Q_LAUNCH(1024, 16) else THR_Q_LAUNCH(1024, 32) break;
         default: return THR_ERR_UNSUPPORTED;
     }
 #undef THR_Q_LAUNCH
@@ -1718,7 +1719,7 @@ static int launch_pack_queries(int dim, const float* queries, int n_queries, int
     switch (dim) {
         case 512: if (s16) THR_PACK(512, 16); else THR_PACK(512, 32); break;
         case 768: if (s16) THR_PACK(768, 16); else THR_PACK(768, 32); break;
-        case 1024: THR_PACK(1024, 32); break;
+        case 1024: if (s16) THR_PACK(1024, 16); else THR_PACK(1024, 32); break;
         default: return THR_ERR_UNSUPPORTED;
     }
 #undef THR_PACK

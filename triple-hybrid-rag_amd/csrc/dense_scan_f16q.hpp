@@ -158,221 +158,6 @@ __device__ __forceinline__ void qs_fill(f32x4 (&a)[Q_RING], uint32_t abase) {
         qs_fill<S + 1, HS>(a, abase);
     }
 }
-// K0 = first k-step of this half (0 or HS) in the B operand array
-template <int S, int HS, int K0, int KS, int PER, typename Issue>
-__device__ __forceinline__ void qs_steps(f32x4 (&a)[Q_RING], const f32x4 (&bq)[KS], f32x16& acc,
-                                         uint32_t abase, Issue& issue_piece) {
-    if constexpr (S < HS) {
-        constexpr int left = HS - S - 1 < Q_RING - 1 ? HS - S - 1 : Q_RING - 1;
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % Q_RING]) : "n"(left) : "memory");
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[S % Q_RING]),
-                                                     __builtin_bit_cast(half8, bq[K0 + S]), acc, 0, 0, 0);
-        if constexpr (S + Q_RING < HS) QS_RD(a[S % Q_RING], S + Q_RING);
-        constexpr int every = HS / PER;
-        if constexpr (S % every == 1 && S / every < PER) issue_piece(std::integral_constant<int, S / every>{});
-        qs_steps<S + 1, HS, K0, KS, PER>(a, bq, acc, abase, issue_piece);
-    }
-}
-#undef QS_RD
-
-// PROF: diagnostic build (thr_dense_scan_stamps_f16): s_memtime stamps around the phases of the
-// half-tile loop, summed per wave into stamps[(block * 4 + wave) * 8 + {0: wait for the own DMA
-// pieces, 1: barrier, 2: ring fill, 3: k-loop (with the DMA issue), 4: emit, 5: half tiles,
-// 6: whole loop, 7: HW_ID}].  Each stamp drains the wave's LDS/SMEM queue, so the build is slower
-// than the real one; it only says where the time goes.
-template <int DIM, int MODE, bool PROF = false>
-__global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q(
-    const f32x4* __restrict__ packed, const f32x4* __restrict__ qfrag, int n_qtiles,
-    int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
-    int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
-    float* __restrict__ sample_scores, int64_t sample_ld,
-    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll, int n_queries,
-    unsigned long long* __restrict__ stamps = nullptr) {
-    using C = QScan<DIM>;
-    constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER;
-    extern __shared__ f32x4 lds_rows[];  // NB half-tile buffers
-
-    const ScanSlot slot = scan_slot(n_qtiles);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const int q32 = slot.qtile * Q_NW + wave;  // this wave's tile of 32 queries
-
-    // B operands: the wave's 32 queries, all k-steps, in registers for the whole launch
-    f32x4 bq[KS];
-    if ((int64_t)q32 * 32 < n_queries)
-        static_for<0, KS>([&](auto s) {
-            bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
-        });
-    const float my_tau = MODE == MODE_FILTER ? tau[q32 * 32 + c] : 0.f;
-    // collection filter of this lane's query (-1: none): checked only for rows that pass tau
-    const int my_qc = (MODE == MODE_FILTER && query_coll && q32 * 32 + c < n_queries) ? query_coll[q32 * 32 + c] : -1;
-    // Retire these loads HERE, visibly to hipcc: left pending, their first use (the first MFMA
-    // of the tile loop) gets an s_waitcnt vmcnt(0) on every trip, which would drain the DMA
-    // of the next half tiles each time.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    // the lane's private candidate segment (MODE_FILTER): query q32*32+c, segment 2*slice + h
-    const int nseg = 2 * slot.nslices;
-    const int64_t my_seg = (int64_t)(q32 * 32 + c) * nseg + 2 * slot.slice + h;
-    Cand* const seg = cand + (int64_t)(q32 * 32 + c) * CAND_CAP + (int64_t)(2 * slot.slice + h) * seg_cap;
-    int cur = 0;
-
-    // this block's row tiles: slice, slice + nslices, ...; half tile j = (tile j/2, dims half j&1)
-    const int64_t first = slot.slice, step = slot.nslices;
-    const int64_t n_mine = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
-    const int64_t n_half = 2 * n_mine;
-    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_rows;
-    // piece p (wave + 4 p) of the block's j-th half tile -> buffer buf; past the end the last
-    // half tile is requested again (never read): the count of pieces in flight stays what the
-    // vmcnt waits assume
-    auto piece_src = [&](int64_t j) -> const f32x4* {
-        const int64_t jc = j < n_half ? j : n_half - 1;
-        const int64_t t = first + (jc >> 1) * step;
-        return packed + ((t * tile_stride * KS + (jc & 1) * HS + wave) * 64 + lane);
-    };
-    auto dma = [&](const f32x4* src, int buf, int p) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + p * Q_NW * 64),
-            (__attribute__((address_space(3))) void*)(size_t)(lds_base + buf * C::HALF_BYTES +
-                                                              (wave + p * Q_NW) * 1024),
-            16, 0, 0);
-    };
-    if (n_half > 0) {
-#pragma unroll
-        for (int b = 0; b < NB - 1; ++b) {
-            const f32x4* src = piece_src(b);
-#pragma unroll
-            for (int p = 0; p < PER; ++p) dma(src, b, p);
-        }
-    }
-
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_loop = 0, t_prev = 0;
-    auto stamp = [&](int j) {
-        if constexpr (PROF) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            if (j >= 0) ph[j] += t - t_prev;
-            t_prev = t;
-        }
-    };
-    if constexpr (PROF) t_loop = __builtin_amdgcn_s_memtime();
-
-    f32x16 acc;
-    int buf = 0;
-    // one trip = one row tile = two half tiles (the accumulators run through both)
-#pragma unroll 1
-    for (int64_t i = 0; i < n_mine; ++i) {
-        // (a macro, not a lambda: asm operands do not capture)
-#define QS_HALF(hf)                                                                                \
-    {                                                                                              \
-        stamp(-1);                                                                                 \
-        /* own pieces of half tile 2i+hf done (the NB-2 younger half tiles' pieces -- and the      \
-           emit's few stores among them, which are over-waited for -- may stay in flight) */       \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
-        stamp(0);                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                              \
-        stamp(1);                                                                                  \
-        const int nbuf = buf == 0 ? NB - 1 : buf - 1; /* half tile j-1's buffer */                 \
-        const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
-        auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
-        const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
-        f32x4 a[Q_RING];                                                                           \
-        qs_fill<0, HS>(a, abase);                                                                  \
-        stamp(2);                                                                                  \
-        qs_steps<0, HS, (hf) * HS, KS, PER>(a, bq, acc, abase, issue_piece);                       \
-        if constexpr (PROF) asm volatile("" : "+v"(acc));                                          \
-        stamp(3);                                                                                  \
-        buf = buf + 1 == NB ? 0 : buf + 1;                                                         \
-    }
-#pragma unroll
-        for (int x = 0; x < 16; ++x) acc[x] = 0.f;
-        QS_HALF(0)
-        QS_HALF(1)
-#undef QS_HALF
-
-        const int64_t t = first + i * step;
-        if constexpr (MODE == MODE_ALL) {
-            // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
-            float* dst = sample_scores + (int64_t)(q32 * 32 + c) * sample_ld + t * 32 + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float sv = acc[4 * g + j];
-                    v[j] = sv == sv ? sv : -INFINITY;  // NaN: no such row / no embedding
-                }
-                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
-            }
-        } else {
-            const uint32_t row0 = (uint32_t)(t * tile_stride * 32) + 4 * h;
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                if (acc[x] >= my_tau) {  // false for NaN
-                    const uint32_t row = row0 + (uint32_t)((x & 3) + 8 * (x >> 2));
-                    // (a filtered query pays a dependent gather here, and its wait drains the DMA
-                    // queue: the price of the WHERE clause, paid by filtered queries only)
-                    if (my_qc != -1 && doc_coll[row] != my_qc) continue;
-                    if (cur < seg_cap) {
-                        // (inline asm: a store hipcc can see would make it wait vmcnt(0) -- DMA
-                        // included -- at the loop's back edge)
-                        const uint64_t word = (uint64_t)__float_as_uint(acc[x]) | ((uint64_t)row << 32);
-                        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(seg + cur), "v"(word) : "memory");
-                    }
-                    ++cur;
-                }
-            }
-        }
-        stamp(4);
-    }
-    // nothing may still be landing in LDS when the block retires
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (MODE == MODE_FILTER) seg_cnt[my_seg] = cur;
-    if constexpr (PROF) {
-        if (lane == 0) {
-            unsigned long long* o = stamps + ((int64_t)blockIdx.x * Q_NW + wave) * 8;
-            for (int j = 0; j < 5; ++j) o[j] = ph[j];
-            o[5] = (unsigned long long)n_half;
-            o[6] = __builtin_amdgcn_s_memtime() - t_loop;
-            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// dense_scan_f16qs: the same scan with ONE 8-wave block per CU (256 queries) whose two wave groups
-// run STAGGERED by half a tile -- the default at dim <= 768.
-//
-// What the counters of the two-blocks-per-CU kernel above said (profiles/r2_scan_v2_*.json): pipe
-// 64 % busy; the older block of a CU wins the matrix pipe and retires when 3/4 of the launch is
-// over, so the pipe is half empty for the last quarter; every CU pulls each tile twice; and the
-// chip drops its clock to 1.5-1.7 GHz under the load.  Here the 8 waves share each half tile
-// (half the DMA pieces and L2 bytes per flop) and are kept in step by one barrier per half tile,
-// but group B (waves 4-7, the younger wave of each SIMD) works one half tile behind group A:
-//
-//     interval k       A (waves 0-3)                        B (waves 4-7)
-//     k = 2i           MFMA half 2i   (k-steps 0..HS)       MFMA half 2i-1 (second half of tile i-1)
-//     k = 2i+1         MFMA half 2i+1, then EMIT tile i     EMIT tile i-1, then MFMA half 2i
-//
-// so an emit always runs under the other group's MFMAs (A is the older wave of the SIMD and gets
-// the pipe first: its MFMAs cover B's emit at the start of the interval, B's cover A's at the
-// end), and B -- whose half tile was published one barrier earlier -- has its first fragments in
-// registers before the barrier opens, which covers A's LDS latency after it.
-// Barrier k: every wave has waited for its own pieces of half tile k (3 younger half tiles'
-// pieces stay in flight); afterwards A is done with half k-1 and B with half k-2, so half k-2's
-// buffer takes the pieces of half k+4: ring of 6 half-tile buffers (144 KiB at dim 768).
-// ---------------------------------------------------------------------------------------------
-constexpr int QS_NW = 8;
-constexpr int QS_NBUF = 6;
-
-template <int DIM>
-struct QStag {
-    static constexpr int KS = DIM / 16, HS = KS / 2, HALF_BYTES = HS * 1024;
-    static constexpr int PER = HS / QS_NW;               // pieces a wave issues per half tile
-    static constexpr int LDS_BYTES = QS_NBUF * HALF_BYTES;
-    static_assert(HS % QS_NW == 0 && LDS_BYTES <= 160 * 1024, "dim 512 / 768 only");
-};
-
 // SHAPE = 32: v_mfma_f32_32x32x16_f16, one MFMA per 1 KiB piece (piece = 32 rows x 16 dims).
 // SHAPE = 16: v_mfma_f32_16x16x32_f16, two MFMAs per piece (piece = 16 rows x 32 dims, against the
 //             wave's two 16-query halves).  Same bytes, same cadence (a piece per 32 matrix-pipe
@@ -414,8 +199,6 @@ struct QAcc<16> {
     static __device__ __forceinline__ int seg(int lane) { return lane >> 4; }
 };
 
-#define QS_RD(dst, ks) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"((ks) * 1024) : "memory")
 // piece S of a half tile (HS pieces): SHAPE 32 -> k-step K0 + S; SHAPE 16 -> row half S & 1 of
 // k32-step (K0 + S) / 2, B operands bq[qb * KS/2 + k32]
 template <int S, int HS, int K0, int KS, int PER, int SHAPE, typename Issue>
@@ -478,6 +261,229 @@ struct QEmit {
             all<X + 1>(acc, row0, lane);
         }
     }
+};
+
+// PROF: diagnostic build (thr_dense_scan_stamps_f16): s_memtime stamps around the phases of the
+// half-tile loop, summed per wave into stamps[(block * 4 + wave) * 8 + {0: wait for the own DMA
+// pieces, 1: barrier, 2: ring fill, 3: k-loop (with the DMA issue), 4: emit, 5: half tiles,
+// 6: whole loop, 7: HW_ID}].  Each stamp drains the wave's LDS/SMEM queue, so the build is slower
+// than the real one; it only says where the time goes.
+template <int DIM, int MODE, bool PROF = false, int SHAPE = 32>
+__global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q(
+    const f32x4* __restrict__ packed, const f32x4* __restrict__ qfrag, int n_qtiles,
+    int64_t n_tiles, int64_t tile_stride, const float* __restrict__ tau,
+    int* __restrict__ seg_cnt, Cand* __restrict__ cand, int seg_cap,
+    float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll, int n_queries,
+    unsigned long long* __restrict__ stamps = nullptr) {
+    using C = QScan<DIM>;
+    using A = QAcc<SHAPE>;
+    constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER, NQL = A::NQL;
+    extern __shared__ f32x4 lds_rows[];  // NB half-tile buffers
+
+    const ScanSlot slot = scan_slot(n_qtiles);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q32 = slot.qtile * Q_NW + wave;  // this wave's tile of 32 queries
+    const bool idle = (int64_t)q32 * 32 >= n_queries;   // all padding: only moves row pieces
+
+    // B operands: the wave's 32 queries, all k-steps, in registers for the whole launch
+    f32x4 bq[KS];
+    if (!idle)
+        static_for<0, KS>([&](auto s) {
+            bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+        });
+    // the lane's private candidate segments (MODE_FILTER): query q, segment SEGS * slice + seg(lane)
+    const int nseg = A::SEGS * slot.nslices;
+    const int my_seg = A::SEGS * slot.slice + A::seg(lane);
+    QEmit<SHAPE> em;
+    em.cand = cand;
+    em.doc_coll = doc_coll;
+    uint32_t start[NQL];
+#pragma unroll
+    for (int u = 0; u < NQL; ++u) {
+        const int q = q32 * 32 + A::query(lane, u);
+        em.tau[u] = MODE == MODE_FILTER ? tau[q] : 0.f;
+        // collection filter of this lane's query (-1: none): checked only for rows that pass tau
+        em.qc[u] = (MODE == MODE_FILTER && query_coll && q < n_queries) ? query_coll[q] : -1;
+        start[u] = (uint32_t)(((int64_t)q * CAND_CAP + (int64_t)my_seg * seg_cap) * sizeof(Cand));
+        em.slot[u] = start[u];
+        em.end[u] = start[u] + (uint32_t)(seg_cap * sizeof(Cand));
+    }
+    // Retire these loads HERE, visibly to hipcc: left pending, their first use (the first MFMA
+    // of the tile loop) gets an s_waitcnt vmcnt(0) on every trip, which would drain the DMA
+    // of the next half tiles each time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    // this block's row tiles: slice, slice + nslices, ...; half tile j = (tile j/2, dims half j&1)
+    const int64_t first = slot.slice, step = slot.nslices;
+    const int64_t n_mine = first < n_tiles ? (n_tiles - first + step - 1) / step : 0;
+    const int64_t n_half = 2 * n_mine;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)lds_rows;
+    // piece p (wave + 4 p) of the block's j-th half tile -> buffer buf; past the end the last
+    // half tile is requested again (never read): the count of pieces in flight stays what the
+    // vmcnt waits assume
+    auto piece_src = [&](int64_t j) -> const f32x4* {
+        const int64_t jc = j < n_half ? j : n_half - 1;
+        const int64_t t = first + (jc >> 1) * step;
+        return packed + ((t * tile_stride * KS + (jc & 1) * HS + wave) * 64 + lane);
+    };
+    auto dma = [&](const f32x4* src, int buf, int p) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + p * Q_NW * 64),
+            (__attribute__((address_space(3))) void*)(size_t)(lds_base + buf * C::HALF_BYTES +
+                                                              (wave + p * Q_NW) * 1024),
+            16, 0, 0);
+    };
+    if (n_half > 0) {
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) {
+            const f32x4* src = piece_src(b);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, b, p);
+        }
+    }
+
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, t_loop = 0, t_prev = 0;
+    auto stamp = [&](int j) {
+        if constexpr (PROF) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (j >= 0) ph[j] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if constexpr (PROF) t_loop = __builtin_amdgcn_s_memtime();
+
+    A acc;
+    int buf = 0;
+    if (idle) {
+        // same barriers, same DMA order and wait counts as a working wave; no LDS reads, no
+        // MFMAs, nothing to emit (see dense_scan_f16qs below)
+#pragma unroll 1
+        for (int64_t j = 0; j < n_half; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nbuf = buf == 0 ? NB - 1 : buf - 1;
+            const f32x4* src = piece_src(j + NB - 1);
+#pragma unroll
+            for (int p = 0; p < PER; ++p) dma(src, nbuf, p);
+            buf = buf + 1 == NB ? 0 : buf + 1;
+        }
+    }
+    // one trip = one row tile = two half tiles (the accumulators run through both)
+#pragma unroll 1
+    for (int64_t i = 0; i < (idle ? 0 : n_mine); ++i) {
+        // (a macro, not a lambda: asm operands do not capture)
+#define QS_HALF(hf)                                                                                \
+    {                                                                                              \
+        stamp(-1);                                                                                 \
+        /* own pieces of half tile 2i+hf done (the NB-2 younger half tiles' pieces -- and the      \
+           emit's few stores among them, which are over-waited for -- may stay in flight) */       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
+        stamp(0);                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                              \
+        stamp(1);                                                                                  \
+        const int nbuf = buf == 0 ? NB - 1 : buf - 1; /* half tile j-1's buffer */                 \
+        const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
+        auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
+        const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
+        f32x4 a[Q_RING];                                                                           \
+        qs_fill<0, HS>(a, abase);                                                                  \
+        stamp(2);                                                                                  \
+        qsx_steps<0, HS, (hf) * HS, KS, PER, SHAPE>(a, bq, acc, abase, issue_piece);                \
+        if constexpr (PROF) {                                                                      \
+            if constexpr (SHAPE == 32) asm volatile("" : "+v"(acc.v));                               \
+            else asm volatile("" : "+v"(acc.t[0]), "+v"(acc.t[1]), "+v"(acc.t[2]), "+v"(acc.t[3])); \
+        }                                                                                          \
+        stamp(3);                                                                                  \
+        buf = buf + 1 == NB ? 0 : buf + 1;                                                         \
+    }
+        acc.zero();
+        QS_HALF(0)
+        QS_HALF(1)
+#undef QS_HALF
+
+        const int64_t t = first + i * step;
+        if constexpr (MODE == MODE_ALL) {
+            if constexpr (SHAPE == 32) {
+                // accumulator registers 4g..4g+3 are 4 consecutive rows: one 16-byte store each
+                float* dst = sample_scores + (int64_t)(q32 * 32 + (lane & 31)) * sample_ld + t * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sv = acc.v[4 * g + j];
+                        v[j] = sv == sv ? sv : -INFINITY;  // NaN: no such row / no embedding
+                    }
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {   // tile (ra, qb): rows 16 ra + 4 g .. + 4 of query 16 qb + c
+                    f32x4 v = acc.t[x];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] == v[j] ? v[j] : -INFINITY;
+                    float* dst = sample_scores + (int64_t)(q32 * 32 + 16 * (x & 1) + (lane & 15)) * sample_ld +
+                                 t * 32 + 16 * (x >> 1) + 4 * (lane >> 4);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        } else {
+            em.template all<0>(acc, (uint32_t)(t * tile_stride * 32), lane);
+        }
+        stamp(4);
+    }
+    // nothing may still be landing in LDS when the block retires
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE == MODE_FILTER) {
+#pragma unroll
+        for (int u = 0; u < NQL; ++u)
+            seg_cnt[(int64_t)(q32 * 32 + A::query(lane, u)) * nseg + my_seg] = (int)((em.slot[u] - start[u]) / sizeof(Cand));
+    }
+    if constexpr (PROF) {
+        if (lane == 0) {
+            unsigned long long* o = stamps + ((int64_t)blockIdx.x * Q_NW + wave) * 8;
+            for (int j = 0; j < 5; ++j) o[j] = ph[j];
+            o[5] = (unsigned long long)n_half;
+            o[6] = __builtin_amdgcn_s_memtime() - t_loop;
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense_scan_f16qs: the same scan with ONE 8-wave block per CU (256 queries) whose two wave groups
+// run STAGGERED by half a tile -- the default at dim <= 768.
+//
+// What the counters of the two-blocks-per-CU kernel above said (profiles/r2_scan_v2_*.json): pipe
+// 64 % busy; the older block of a CU wins the matrix pipe and retires when 3/4 of the launch is
+// over, so the pipe is half empty for the last quarter; every CU pulls each tile twice; and the
+// chip drops its clock to 1.5-1.7 GHz under the load.  Here the 8 waves share each half tile
+// (half the DMA pieces and L2 bytes per flop) and are kept in step by one barrier per half tile,
+// but group B (waves 4-7, the younger wave of each SIMD) works one half tile behind group A:
+//
+//     interval k       A (waves 0-3)                        B (waves 4-7)
+//     k = 2i           MFMA half 2i   (k-steps 0..HS)       MFMA half 2i-1 (second half of tile i-1)
+//     k = 2i+1         MFMA half 2i+1, then EMIT tile i     EMIT tile i-1, then MFMA half 2i
+//
+// so an emit always runs under the other group's MFMAs (A is the older wave of the SIMD and gets
+// the pipe first: its MFMAs cover B's emit at the start of the interval, B's cover A's at the
+// end), and B -- whose half tile was published one barrier earlier -- has its first fragments in
+// registers before the barrier opens, which covers A's LDS latency after it.
+// Barrier k: every wave has waited for its own pieces of half tile k (3 younger half tiles'
+// pieces stay in flight); afterwards A is done with half k-1 and B with half k-2, so half k-2's
+// buffer takes the pieces of half k+4: ring of 6 half-tile buffers (144 KiB at dim 768).
+// ---------------------------------------------------------------------------------------------
+constexpr int QS_NW = 8;
+constexpr int QS_NBUF = 6;
+
+template <int DIM>
+struct QStag {
+    static constexpr int KS = DIM / 16, HS = KS / 2, HALF_BYTES = HS * 1024;
+    static constexpr int PER = HS / QS_NW;               // pieces a wave issues per half tile
+    static constexpr int LDS_BYTES = QS_NBUF * HALF_BYTES;
+    static_assert(HS % QS_NW == 0 && LDS_BYTES <= 160 * 1024, "dim 512 / 768 only");
 };
 
 template <int DIM, int MODE, int SHAPE = 32>
