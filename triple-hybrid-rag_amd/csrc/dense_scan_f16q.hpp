@@ -1,5 +1,9 @@
 // Shortlist scan with the QUERIES in registers and the ROWS shared through LDS
 // (thr_dense_topk_f16 over the fragment-major float16 copy; the default f16 scan since round 2).
+// Two kernels share the pieces below (QAcc / qsx_steps / QEmit: the MFMA shape, the k-loop of a
+// half tile, the per-lane segment emit): dense_scan_f16q, described first -- 4-wave blocks, the
+// kernel of dim 1024 -- and dense_scan_f16qs further down, the staggered 8-wave block that is
+// the default at dim <= 768.
 //
 // Why (profiles/README.md, round 2): the round-1 kernel (dense_scan_f16p) kept 96 queries in
 // LDS and let every wave stream its own rows from L2 -- 8 KiB of row fragments per 24 MFMAs and
@@ -31,11 +35,12 @@
 // is then the scan score itself (no 1/||d|| gather) and `acc >= tau` is false for every row that
 // must not be emitted -- the fast path of the epilogue is one compare + branch per accumulator
 // register.  A lane that passes writes (score, row) straight to global memory at its OWN cursor:
-// lane (query c, row half h) of the block working on row slice `slice` owns segment
-// 2 * slice + h of query c's candidate area, so there is no staging, no atomic and no flush --
-// the 1400 cycles per tile the LDS-staged, atomically flushed emit of the first version took
-// (the returning atomics also drained the DMA queue).  select_rescore reads the segments in
-// place (cand_cnt[q * nseg + s] entries each).
+// lane (query c, row group g) of the block working on row slice `slice` owns segment
+// SEGS * slice + g of query c's candidate area (SEGS = 2 row halves with the 32x32x16 MFMA shape,
+// 4 row groups with 16x16x32), so there is no staging, no atomic and no flush -- the 1400 cycles
+// per tile the LDS-staged, atomically flushed emit of the first version took (the returning
+// atomics also drained the DMA queue).  select_band reads the segments in place
+// (cand_cnt[q * nseg + s] entries each).
 #pragma once
 
 namespace thr {
