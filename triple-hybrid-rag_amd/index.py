@@ -75,7 +75,7 @@ class GpuIndex:
 
     SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
     F16_DIMS = (512, 768, 1024)
-    AUTO_COPY_FRACTION = 0.10
+    AUTO_COPY_FRACTION = 0.25    # of the device's memory: every shard the f16 scans can index (2^25 rows)
     F16_MAX_ROWS = 1 << 25       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
     F16_MAX_REL_ERR = 2e-3       # ~8x the rounding error of rows in float16's normal range
 
@@ -88,7 +88,8 @@ class GpuIndex:
           "f16"        additionally keeps a float16 copy of the rows and streams that;
           "auto"       an f16 flavour when the dimension has an f16 kernel and every row fits the
                        float16 range -- "f16" while the copy is small next to the device's memory
-                       (<= AUTO_COPY_FRACTION of it), "f16-inline" beyond -- else "f32"."""
+                       (<= AUTO_COPY_FRACTION of it: a quarter, which covers every shard size the f16 scans
+                       index), "f16-inline" beyond -- else "f32"."""
         if shortlist not in self.SHORTLISTS:
             raise ValueError(f"shortlist must be one of {self.SHORTLISTS}")
         self.docs = self._t(docs, torch.float32)
