@@ -1110,6 +1110,40 @@ def test_hybrid_rrf_rpc_and_legacy_searcher_on_gpu(T):
         assert [r.chunk_id for r in out] == [e["chunk_id"] for e in exp]
         assert [r.rrf_score for r in out] == [e["rrf_score"] for e in exp]
 
+    # the image channel (hybrid_search.py:423-458, kb_chunks_image_search): every 7th chunk has an
+    # image vector; three lists fuse (vector, bm25, image with top_k_image = 3)
+    rng = np.random.default_rng(77)
+    img_rows = np.arange(0, n, 7)
+    xi = rng.standard_normal((len(img_rows), 768)).astype(np.float32)
+    img_idx = T.GpuIndex().set_dense(xi)
+    client_i = GpuIndexClient(idx, client.store, org_id="org", image_index=img_idx, image_rows=img_rows)
+    qimg = (xi[123] + 0.4 * rng.standard_normal(768)).astype(np.float32)
+    rows = client_i.rpc("kb_chunks_image_search", {"p_org_id": "org", "p_image_embedding": qimg.tolist(),
+                                                   "p_limit": 5}).execute().data
+    si = O.cosine_scores_f64(xi, qimg)
+    ts, ti = O.topk_desc(si, 5)
+    assert [r["id"] for r in rows] == [f"c{int(img_rows[j])}" for j in ti] and rows[0]["id"] == f"c{int(img_rows[123])}"
+    assert [r["similarity"] for r in rows] == [float(np.float32(v)) for v in ts]
+    terms = [100, 2000, 77]
+    text = " ".join(f"t{t}" for t in terms)
+
+    class EmbI:
+        def embed_query(self, text, _v=q[0].tolist(), _i=qimg.tolist()):
+            return _v, _i
+
+    hs = HybridSearcher("org", embedder=EmbI(),
+                        config=SearchConfig(top_k_retrieve=50, use_image_search=True))._with(client_i)
+    out = asyncio.run(hs.search(text, top_k=10))
+    _, Id50, _ = CO.dense_topk_exact(x, q[0:1], 50)
+    _, Il50 = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [terms], n, 50)
+    _, ti3 = O.topk_desc(si, 3)
+    exp = O.legacy_rrf_fusion([[{"chunk_id": f"c{i}"} for i in Id50[0]],
+                               [{"chunk_id": f"c{i}"} for i in Il50[0]],
+                               [{"chunk_id": f"c{int(img_rows[j])}"} for j in ti3]], 60)[:10]
+    assert [r.chunk_id for r in out] == [e["chunk_id"] for e in exp]
+    assert [r.rrf_score for r in out] == [e["rrf_score"] for e in exp]
+    assert f"c{int(img_rows[123])}" in [r.chunk_id for r in out]       # 1/61 ranks it with the best
+
 
 def test_dense_rows_below_half_precision_range(T):
     """Rows scaled into float16's subnormal range: the in-flight-rounding scan refuses them, the

@@ -121,11 +121,20 @@ class GpuIndexClient:
     """Supabase-shaped facade over (GpuIndex, CorpusStore)."""
 
     def __init__(self, index: GpuIndex, store: CorpusStore, org_id: Optional[str] = None,
-                 token_embedder: Any = None, lexical_and: bool = False):
+                 token_embedder: Any = None, lexical_and: bool = False,
+                 image_index: Optional[GpuIndex] = None, image_rows: Any = None):
         """lexical_and: rank only chunks holding EVERY query term, as the reference's
         ``plainto_tsquery`` does (rag2_schema.sql:365); default is BM25's OR form, the
-        north star's and the oracle's."""
+        north star's and the oracle's.
+        image_index / image_rows: the legacy image channel (``kb_chunks_image_search``,
+        20260113_add_kb_chunks.sql:236-268): a second dense index over the ``vector_image`` of the
+        chunks that have one (``vector_image IS NOT NULL``), row j of it being store row
+        ``image_rows[j]``."""
         self.lexical_and = bool(lexical_and)
+        self.image_index = image_index
+        self.image_rows = None if image_rows is None else [int(r) for r in image_rows]
+        if (image_index is None) != (image_rows is None):
+            raise ValueError("image_index and image_rows come together")
         self.index = index
         self.store = store
         self.org_id = org_id
@@ -164,7 +173,27 @@ class GpuIndexClient:
         if name == "kb_chunks_fts_pt":          # legacy RAG 1.0 (20260113_add_kb_chunks.sql:152-190)
             rows = self._lexical(params["p_query"], int(params.get("p_limit", 50)), None)
             return _Reply([self._legacy_row(r, "rank") for r in rows])
+        if name == "kb_chunks_image_search":    # legacy RAG 1.0 (20260113_add_kb_chunks.sql:236-268)
+            return _Reply(self._image(params["p_image_embedding"], int(params.get("p_limit", 10))))
         raise ValueError(f"unknown RPC {name!r}")
+
+    def _image(self, embedding, limit: int) -> List[Dict[str, Any]]:
+        """Cosine top-``limit`` over the image vectors (exact; the SQL orders by ``<=>``)."""
+        if self.image_index is None:
+            return []
+        q = torch.tensor([list(map(float, embedding))], dtype=torch.float32,
+                         device=self.image_index.device)
+        if q.shape[1] != self.image_index.dim:
+            raise ValueError(f"image embedding has {q.shape[1]} dims, index has {self.image_index.dim}")
+        k = min(N.THR_DENSE_MAX_K, limit)
+        S, I, cnt, _ = self.image_index.dense_search(q, k)
+        out = []
+        for j, sc in zip(I[0].tolist()[:int(cnt[0])], S[0].tolist()):
+            row = self.store.result_row(self.image_rows[int(j) - self.image_index.doc_base])
+            out.append({"id": row["child_id"], "content": row["text"], "modality": row["modality"],
+                        "source_document": row["document_id"], "page": row["page"], "alt_text": None,
+                        "image_path": None, "similarity": float(np.float32(sc))})   # ::REAL
+        return out
 
     def _legacy_row(self, row: Dict[str, Any], score_key: str) -> Dict[str, Any]:
         i = self.store.row_index(row["child_id"])

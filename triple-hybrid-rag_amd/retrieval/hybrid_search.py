@@ -5,9 +5,10 @@ Mirrors src/voice_agent/retrieval/hybrid_search.py: ``SearchResult`` (:52-77, wh
 embed -> vector + lexical channels -> unweighted RRF ``1/(k + rank0 + 1)`` -> filters ->
 ``[:top_k]``) and ``_rrf_fusion`` (:460-501: first-seen object kept, best per-channel scores
 kept, stable sort).  The two channel RPCs (``kb_chunks_vector_search``,
-``kb_chunks_fts_pt``) are answered by ``GpuIndexClient`` with thr_dense_topk / thr_bm25_topk;
-the image channel and the ILIKE / np.dot client-side fallbacks (:260-421) have no counterpart
-(there is no second, slower path to fall back to).
+``kb_chunks_fts_pt``) are answered by ``GpuIndexClient`` with thr_dense_topk / thr_bm25_topk, the
+image channel (``_image_search`` :423-458, RPC ``kb_chunks_image_search``) by a second dense index
+over the chunks' image vectors; the ILIKE / np.dot client-side fallbacks (:260-421) have no
+counterpart (there is no second, slower path to fall back to).
 """
 from __future__ import annotations
 
@@ -112,11 +113,14 @@ class HybridSearcher:
             embedded = await embedded
         # the RAG 1.0 embedder returns (text_embedding, image_embedding) (:136)
         text_vec = embedded[0] if isinstance(embedded, tuple) else embedded
+        image_vec = embedded[1] if isinstance(embedded, tuple) and len(embedded) > 1 else None
         jobs = []
         if self.config.use_vector:
             jobs.append(self._vector_search(text_vec, category, source_document))
         if self.config.use_bm25:
             jobs.append(self._bm25_search(query, category, source_document))
+        if self.config.use_image_search and image_vec:
+            jobs.append(self._image_search(image_vec))
         lists = await asyncio.gather(*jobs)
         if self.config.use_hybrid and len(lists) > 1:
             combined = self._rrf_fusion(list(lists))
@@ -138,6 +142,22 @@ class HybridSearcher:
             "p_org_id": self.org_id, "p_query": query,
             "p_limit": self.config.top_k_retrieve}).execute()
         return [_row_to_result(r, "bm25") for r in reply.data]
+
+    async def _image_search(self, image_embedding):
+        """hybrid_search.py:423-458: top ``top_k_image`` chunks by image-vector cosine; a failure
+        of the channel degrades to an empty list, as in the reference."""
+        try:
+            reply = self.supabase.rpc("kb_chunks_image_search", {
+                "p_org_id": self.org_id, "p_image_embedding": image_embedding,
+                "p_limit": self.config.top_k_image}).execute()
+            return [SearchResult(chunk_id=r["id"], content=r["content"], modality=r["modality"],
+                                 source_document=r["source_document"], page=r.get("page") or 1,
+                                 chunk_index=0, similarity_score=r.get("similarity", 0.0),
+                                 alt_text=r.get("alt_text"), retrieval_method="image")
+                    for r in reply.data]
+        except Exception as e:  # noqa: BLE001 -- the reference logs and returns []
+            log.error("Image search failed: %s", e)
+            return []
 
     def _rrf_fusion(self, results_lists: List[List[SearchResult]]) -> List[SearchResult]:
         return rrf_fusion(results_lists, self.config.rrf_k)
