@@ -6,6 +6,7 @@ which is what is asserted); MaxSim within 1e-4 absolute (fp32 MFMA accumulate).
 """
 import os
 import numpy as np
+import torch
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -743,6 +744,44 @@ def test_index_build_rows_through_the_kernels(T, tmp_path):
                          np.array([[vocab[words[3]], vocab[words[11]]]], dtype=np.int32), n, 15,
                          conjunctive=True)
     assert [r["child_id"] for r in rows] == [f"c{int(j)}" for j in Il2[0]]
+
+
+def test_side_stream_channels_equal_the_single_stream_pipeline(T, monkeypatch):
+    """retrieve_batch runs the lexical and graph kernels on a second (high-priority) HIP stream.
+    Twelve batches whose inputs are produced on the main stream right before each call -- by
+    asynchronous host-to-device copies and device ops -- must give what the one-stream pipeline
+    (THR_SIDE_STREAM=0) gives, bit for bit, with the rerank leg on."""
+    from triple_hybrid_rag_amd import synth
+    n, d, nq = 20000, 768, 96
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    g = synth.build_graph(n)
+    dtok = synth.doc_tokens(0, n, 32, 64)
+    idx = (T.GpuIndex().set_dense(x)
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf)
+           .set_tokens(dtok))
+    rng = np.random.default_rng(5)
+    for it in range(12):
+        q = synth.dense_queries(nq, d, n)[rng.permutation(nq)]
+        qt = synth.lexical_queries(nq, csr.df_local, 4)[rng.permutation(nq)]
+        seeds = synth.graph_queries(nq, n, 3)[rng.permutation(nq)]
+        qtok = synth.query_tokens(nq, 32, 64)[rng.permutation(nq)]
+        out = {}
+        for mode in ("0", "hi"):
+            monkeypatch.setenv("THR_SIDE_STREAM", mode)
+            # fresh device tensors every time, some through device-side ops on the main stream
+            qd = torch.from_numpy(q).pin_memory().cuda(non_blocking=True) * 1.0
+            qtd = torch.from_numpy(np.ascontiguousarray(qt)).pin_memory().cuda(non_blocking=True) + 0
+            sd = torch.from_numpy(np.ascontiguousarray(seeds)).pin_memory().cuda(non_blocking=True) + 0
+            qk = torch.from_numpy(qtok).pin_memory().cuda(non_blocking=True)
+            r = idx.retrieve_batch(qd, qtd, sd, top_k=10, qtok=qk, rerank_top_k=50)
+            out[mode] = (r.ids.clone(), r.scores.clone(), r.counts.clone(),
+                         r.channels["lexical"][1].clone(), r.channels["graph"][1].clone())
+            del qd, qtd, sd, qk, r
+        torch.cuda.synchronize()
+        for a, b in zip(out["0"], out["hi"]):
+            assert torch.equal(a, b), it
 
 
 def test_full_size_1m_dense(T):
