@@ -29,6 +29,15 @@ def _worker(rank, world, port, n, d, k, out_dir):
     I = torch.from_numpy(np.stack(I))
     Sg, Ig = gather_topk(S, I)
     assert Sg.shape == (world, 5, k)
+    # several channels in ONE collective: the same lists as one collective per channel gives
+    from triple_hybrid_rag_amd.distributed import gather_topk_many
+    S2, I2 = S[:, : k // 2].contiguous() * 2.0, I[:, : k // 2].contiguous() + 7
+    S3, I3 = S[:, :3].contiguous() - 1.0, I[:, :3].contiguous()
+    many = gather_topk_many([(S, I), (S2, I2), (S3, I3)])
+    for (ms_, mi_), (s_, i_) in zip(many, [(S, I), (S2, I2), (S3, I3)]):
+        es_, ei_ = gather_topk(s_, i_)
+        assert ms_.shape == es_.shape and torch.equal(ms_, es_) and torch.equal(mi_, ei_)
+        assert ms_.stride(2) == 1 and ms_.stride(1) == s_.shape[1] and ms_.stride(0) == mi_.stride(0)
     if rank == 0:
         np.save(os.path.join(out_dir, "S.npy"), Sg.numpy())
         np.save(os.path.join(out_dir, "I.npy"), Ig.numpy())

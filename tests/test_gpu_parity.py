@@ -1059,6 +1059,24 @@ def test_gather_topk_over_rccl_single_rank(T):
         sh.world = 2                      # force the exchange although the group has one rank
         Sx, Ix = sh._merge(S, I, 100)
         assert torch.equal(Ix, I)
+        # several channels in one collective (what ShardedIndex.retrieve_batch sends), merged in
+        # place from the gathered flat buffer
+        from triple_hybrid_rag_amd.distributed import gather_topk_many
+        S2, I2, _, _ = idx.dense_search(dev(q), 50)
+        many = gather_topk_many([(S, I), (S2, I2)])
+        torch.cuda.synchronize()
+        for (Sg2, Ig2), (s_, i_), k_ in zip(many, [(S, I), (S2, I2)], (100, 50)):
+            assert Sg2.shape == (1, 40, k_) and torch.equal(Sg2[0], s_) and torch.equal(Ig2[0], i_)
+            Sm2, Im2, _ = T._native.merge_topk(Sg2, Ig2, k_)
+            assert torch.equal(Im2, i_) and torch.equal(Sm2, s_)
+        # and the whole sharded pipeline over the 1-rank RCCL group
+        csr, idf, avgdl, v = lexical_fixture(T, 20000)
+        idx.set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+        from triple_hybrid_rag_amd import synth
+        qt = synth.lexical_queries(40, csr.df_local, 4)
+        ref = idx.retrieve_batch(dev(q), dev(qt), top_k=10)
+        got = sh.retrieve_batch(dev(q), dev(qt), top_k=10)
+        assert torch.equal(ref.ids, got.ids) and torch.equal(ref.scores, got.scores)
     finally:
         dist.destroy_process_group()
 

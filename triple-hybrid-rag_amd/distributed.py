@@ -80,6 +80,32 @@ def gather_topk(scores: torch.Tensor, ids: torch.Tensor, group=None
     return out[:, 0].view(torch.float64), out[:, 1]
 
 
+def gather_topk_many(pairs, group=None):
+    """The same exchange for SEVERAL channels in ONE collective: ``pairs`` = [(scores [nq, k_c],
+    ids [nq, k_c]), ...] -> [(scores [world, nq, k_c], ids [world, nq, k_c]), ...].  The channels'
+    [2, nq, k_c] tiles travel back to back in one flat int64 buffer (one small packing copy: the
+    exchange is latency-bound -- a collective per channel would pay its latency three times); the
+    results are strided views of the gathered [world, total] buffer, which thr_merge_topk reads
+    in place."""
+    world = dist.get_world_size(group)
+    tiles = [_as_tile(s, i).reshape(-1) for s, i in pairs]
+    flat = tiles[0] if len(tiles) == 1 else torch.cat(tiles)
+    if dist.get_backend(group) == "gloo":
+        host = [torch.empty(flat.shape, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(host, flat.cpu(), group=group)
+        out = torch.stack(host).to(flat.device)
+    else:
+        out = torch.empty((world, flat.numel()), dtype=torch.int64, device=flat.device)
+        dist.all_gather_into_tensor(out, flat, group=group)
+    res, off = [], 0
+    for s, i in pairs:
+        nq, k = i.shape
+        t = out[:, off:off + 2 * nq * k].view(world, 2, nq, k)
+        res.append((t[:, 0].view(torch.float64), t[:, 1]))
+        off += 2 * nq * k
+    return res
+
+
 def gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather one fixed-shape tensor per rank -> [world, *x.shape] (the second exchange of
     the rerank leg: each rank's [nq, n] MaxSim scores, -inf where it does not own the doc)."""
@@ -126,16 +152,25 @@ class ShardedIndex:
         # exchanges stay on the main stream, after the join
         lex, gra, join = L.side_channels(query_terms, lexical_top_k, query_seeds, graph_top_k, hops)
         Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False)
-        Ss, Is = self._merge(Ss, Is, semantic_top_k)
-        ch["semantic"] = (Ss, Is, None)
         join()
-        Il = Ig = None
+        # ONE exchange for all the channels of the batch, then a merge per channel
+        names, locals_, ks = ["semantic"], [(Ss, Is)], [semantic_top_k]
         if lex is not None:
-            Sl, Il = self._merge(lex[0], lex[1], lexical_top_k)
-            ch["lexical"] = (Sl, Il, None)
+            names.append("lexical"); locals_.append((lex[0], lex[1])); ks.append(lexical_top_k)
         if gra is not None:
-            Sg, Ig = self._merge(gra[0], gra[1], graph_top_k)
-            ch["graph"] = (Sg, Ig, None)
+            names.append("graph"); locals_.append((gra[0], gra[1])); ks.append(graph_top_k)
+        if self.world > 1:
+            merged = []
+            for (Sg, Ig_), k in zip(gather_topk_many(locals_, self.group), ks):
+                Sm, Im, _ = N.merge_topk(Sg, Ig_, k)
+                merged.append((Sm, Im))
+        else:
+            merged = locals_
+        for name, (Sm, Im) in zip(names, merged):
+            ch[name] = (Sm, Im, None)
+        Is = ch["semantic"][1]
+        Il = ch["lexical"][1] if "lexical" in ch else None
+        Ig = ch["graph"][1] if "graph" in ch else None
         rerank = qtok is not None and L.tokens is not None
         n_fused = max(rerank_top_k, top_k) if rerank else top_k
         ids, sc, _, cnt = N.rrf_fuse(Il, Is, Ig, n_fused, w["lexical"], w["semantic"], w["graph"])
