@@ -89,21 +89,6 @@ def event_ms(fn, reps, torch):
     return e0.elapsed_time(e1) / reps
 
 
-def device_tokens(torch, start, count, d_tokens=128, tok_dim=128, seed=1234 + 3, block=8192):
-    """Unit-norm float16 token matrices [count, d_tokens, tok_dim] for global docs
-    [start, start+count), generated ON THE DEVICE in blocks seeded by the global block index
-    (a shard holds what the unsharded store holds; 32.8 GB per 1M docs never touches the host)."""
-    out = torch.empty((count, d_tokens, tok_dim), dtype=torch.float16, device="cuda")
-    g = torch.Generator(device="cuda")
-    for b in range(start // block, (start + count - 1) // block + 1):
-        g.manual_seed(seed * 1_000_003 + b)
-        x = torch.randn((block, d_tokens, tok_dim), generator=g, device="cuda", dtype=torch.float32)
-        x = torch.nn.functional.normalize(x, dim=2).to(torch.float16)
-        lo, hi = max(start, b * block), min(start + count, (b + 1) * block)
-        out[lo - start:hi - start] = x[lo - b * block:hi - b * block]
-    return out
-
-
 def main():
     args = parse()
     import torch
@@ -178,7 +163,7 @@ def main():
         seeds = synth.graph_queries(nq * n_replicas, args.docs, 3)[replica::n_replicas]
     if need_tok:
         n_tok = min(n_local, args.token_docs) if args.token_docs else n_local
-        index.set_tokens(device_tokens(torch, lo, n_tok))
+        index.set_tokens(synth.device_tokens(lo, n_tok))
         g = torch.Generator(device="cuda")
         g.manual_seed(4321 + 3)
         qtok = torch.nn.functional.normalize(torch.randn((nq * n_replicas, 32, 128), generator=g, device="cuda"),
@@ -456,7 +441,7 @@ def main():
                         continue    # regenerated block by block on the device and copied back
                     rows_ = {}
                     for b in sorted({d // block for d in fi}):
-                        blk = device_tokens(torch, b * block, min(block, n_local - b * block))
+                        blk = synth.device_tokens(b * block, min(block, n_local - b * block))
                         for d in fi:
                             if d // block == b:
                                 rows_[d] = blk[d - b * block].cpu().numpy()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 4
+#define THR_ABI_VERSION 5
 
 typedef void *thr_stream_t;
 
@@ -79,9 +79,12 @@ int thr_doc_norms(const float *docs, int64_t n_docs, int dim, double *dnorm, flo
  * called from src/voice_agent/rag2/retrieval.py:304-312, and the client-side
  * np.dot fallback src/voice_agent/retrieval/hybrid_search.py:285-316.
  *
- * Pass 1 streams the corpus once per tile of queries in float32 and keeps a
- * shortlist of k' = ``kprime`` rows per query; pass 2 rescans the shortlist in
- * float64 (sequential accumulation, the oracle's contract) and orders it.
+ * Pass 1 (this entry point: the fp32 matrix cores, 32 queries per workgroup and pass over a
+ * row slice; thr_dense_topk_f16 below: f16 matrix cores over a float16 copy or over rows
+ * rounded in flight) finds per query a threshold tau from a row sample, streams the corpus and
+ * emits the rows scoring >= tau; pass 2 takes from those the band that can still reach the top
+ * k' = ``kprime``, rescores it in float64 (sequential accumulation, the oracle's contract)
+ * from the float32 rows and orders it.
  * out_flags[q] has THR_FLAG_CERTIFIED when the float32 error bound proves the
  * top-k exact; otherwise call thr_dense_topk_exact for that query.
  * Outputs are padded with (-inf, -1) beyond out_counts[q]. */
@@ -145,6 +148,10 @@ int thr_dense_rescue(const float *docs, const double *dnorm, int64_t n_docs, int
 size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim);
 /* queries per workgroup (= per pass over a row slice) of the f16 scan */
 int thr_dense_f16_query_tile(int dim, int packed /* docs16 != NULL */, int n_queries);
+/* largest n_queries of ONE thr_dense_topk_f16 call: the copy scan addresses a lane's candidate
+ * segment with a 32-bit byte offset (131072 bytes of candidate area per query), so a larger
+ * batch returns THR_ERR_UNSUPPORTED and the caller splits it (GpuIndex.dense_search does). */
+int thr_dense_f16_max_queries(int dim, int packed /* docs16 != NULL */);
 int thr_dense_quantize_f16(const float *docs, int64_t n_docs, int dim,
                            uint16_t *docs16 /* thr_dense_f16_copy_bytes(...) bytes, or NULL */,
                            float *max_rel_err, thr_stream_t stream);
@@ -200,13 +207,21 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * [nq] (both or neither; query_coll -1 = unfiltered): only docs of the query's collection are
  * ranked, BEFORE the top-k -- ``AND (p_collection IS NULL OR d.collection = p_collection)``,
  * rag2_schema.sql:368-373. */
+/* Work decomposition (ABI 5): queries whose lists hold >= 24576 postings are cut into doc-range
+ * slices (up to 128, equal shares of the query's longest list), every slice is a work item of a
+ * persistent grid, the slices of a query share the pruning threshold through a device-side
+ * atomic max and are merged at the end -- a stop-word query is the job of many workgroups, not
+ * of one.  ``workspace`` >= thr_bm25_workspace_bytes(n_queries, max_terms, k): item list, slice
+ * edges, per-slice lists. */
+size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k);
 int thr_bm25_topk(const int64_t *rowptr /* [V+1] */, const int32_t *post_doc,
                   const int32_t *post_tf, const float *doclen /* [n_docs] */,
                   const double *idf /* [V] */, const double *term_ub, const double *block_ub,
                   double avgdl, double k1, double b, int64_t n_docs, int64_t n_vocab,
                   int64_t id_base, const int32_t *query_terms, int n_queries, int max_terms, int k,
                   int conjunctive, const int32_t *doc_coll, const int32_t *query_coll,
-                  double *out_scores, int64_t *out_ids, int32_t *out_counts, thr_stream_t stream);
+                  double *out_scores, int64_t *out_ids, int32_t *out_counts, void *workspace,
+                  size_t workspace_bytes, thr_stream_t stream);
 
 /* a4  graph channel: bounded BFS (<= hops) from seed entities over the
  * entity CSR, then score(chunk) = sum_e conf(e,chunk)/(1+dist(e)) over the

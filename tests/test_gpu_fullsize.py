@@ -1,0 +1,174 @@
+"""GPU parity at the BASELINE.json sizes: configs[2] (1M docs, dense + BM25 + RRF(0.8/0.7)) and
+ONE rank's shard of configs[3] / configs[4] (10M docs over 8 GPUs: 1.25M rows per GPU, global
+idf / avgdl, replicated entity graph, token store generated on the device) -- every channel's
+per-shard top-k, the fusion and the shard's MaxSim scores against the CPU oracle run on the same
+slice.  ids / order / cosine / BM25 / graph / RRF scores bit-identical; MaxSim within 1e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle as CO  # noqa: E402
+from oracle import thr_oracle as O  # noqa: E402
+
+D = 768
+
+
+@pytest.fixture(scope="module")
+def T():
+    import triple_hybrid_rag_amd as T
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    T._native.load()
+    return T
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def assert_lists_equal(S, I, cnt, Se, Ie, what):
+    S, I, cnt = S.cpu().numpy(), I.cpu().numpy(), cnt.cpu().numpy()
+    for q in range(len(Ie)):
+        n = len(Ie[q])
+        assert int(cnt[q]) == n, f"{what} q{q}: count {cnt[q]} != {n}"
+        assert np.array_equal(I[q, :n], Ie[q]), f"{what} q{q}: ids differ"
+        assert np.array_equal(S[q, :n], Se[q]), f"{what} q{q}: scores differ (bits)"
+
+
+def mixed_lexical_queries(synth, nq, df, n_docs):
+    """Half SURVEY 8(d)'s mix (4 terms sampled in proportion to df: stop words, lists of up to
+    ~n_docs postings, the sliced path of thr_bm25_topk), half the same draw with the terms held
+    by more than 1 % of the docs removed (short lists: one work item per query)."""
+    a = synth.lexical_queries(nq, df, 4)
+    dfq = df.copy()
+    dfq[dfq > 0.01 * n_docs] = 0
+    b = synth.lexical_queries(nq, dfq, 4)
+    a[1::2] = b[1::2]
+    return a
+
+
+def test_config2_1m_dense_bm25_rrf(T):
+    """BASELINE configs[2]: 1M x 768 dense + BM25 (avg 64 postings/term) + RRF(0.8/0.7), 64
+    queries, both channels and the fused top-10 against the oracle; plus thr_doc_norms at 1M rows."""
+    from triple_hybrid_rag_amd import synth
+    n, nq = 1_000_000, 64
+    x = synth.dense_rows(0, n, D)
+    q = synth.dense_queries(nq, D, n)
+    d_, t_, f_ = synth.lexical_rows(0, n, n)
+    v = synth.vocab_size(n)
+    csr = synth.build_lexical_csr(d_, t_, f_, n, v)
+    del d_, t_, f_
+    idf = O.bm25_idf(n, csr.df_local)
+    avgdl = csr.sum_dl_local / n
+    qt = mixed_lexical_queries(synth, nq, csr.df_local, n)
+    idx = T.GpuIndex().set_dense(x).set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+    # the index's norms are the oracle's, bit for bit, on all 1M rows (the oracle below gets its own)
+    dn = CO.doc_norms(x)
+    assert np.array_equal(idx.dnorm.cpu().numpy(), dn)
+    w = {"lexical": 0.7, "semantic": 0.8}
+    res = idx.retrieve_batch(dev(q), dev(qt), None, top_k=10, weights=w)
+    assert int(res.rescued) == 0
+    Sd, Id = O.dense_topk_fast(x, q, 100, dnorm=dn)
+    Sl, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
+    assert_lists_equal(*res.channels["semantic"], Sd, Id, "dense")
+    assert_lists_equal(*res.channels["lexical"], Sl, Il, "bm25")
+    sub = [0, 1, 30, 63]   # the exhaustive float64 scan of the C oracle on a few of them
+    Se, Ie, _ = CO.dense_topk_exact(x, q[sub], 100, dnorm=dn)
+    for j, qi in enumerate(sub):
+        assert np.array_equal(Ie[j], Id[qi]) and np.array_equal(Se[j], Sd[qi])
+    ids, sc, cnt = res.ids.cpu().numpy(), res.scores.cpu().numpy(), res.counts.cpu().numpy()
+    for i in range(nq):
+        ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), None, 10, w)
+        assert list(ids[i, :cnt[i]]) == ei and list(sc[i, :cnt[i]]) == es, f"fused differs for query {i}"
+    # the stop-word half really took the sliced path: lists of >= 24576 postings
+    long_q = [i for i in range(nq) if sum(int(csr.df_local[t]) for t in qt[i] if t >= 0) >= 24576]
+    assert len(long_q) >= nq // 4
+
+
+_GLOBAL = {}
+
+
+def global_lexical_stats(synth, n_global):
+    if n_global not in _GLOBAL:
+        _GLOBAL[n_global] = synth.lexical_global_stats(n_global)
+    return _GLOBAL[n_global]
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_config3_config4_one_shard_of_the_10m_corpus(T, rank):
+    """BASELINE configs[3] / configs[4]: rank ``rank`` of 8 of the 10M-doc corpus -- 1.25M rows,
+    doc_base = lo, idf / avgdl of the WHOLE corpus, the replicated entity graph with this shard's
+    mentions, late-interaction tokens generated on the device.  Per-shard top-k of every channel,
+    the fusion of those lists and the shard's MaxSim scores against the oracle on the same slice."""
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import shard_range
+    n_global, world, nq = 10_000_000, 8, 48
+    lo, hi = shard_range(n_global, rank, world)
+    n = hi - lo
+    assert n == 1_250_000
+    x = synth.dense_rows(lo, n, D)
+    q = synth.dense_queries(nq, D, n_global)
+    df, sum_dl = global_lexical_stats(synth, n_global)
+    v = synth.vocab_size(n_global)
+    idf = O.bm25_idf(n_global, df)
+    avgdl = sum_dl / n_global
+    d_, t_, f_ = synth.lexical_rows(lo, n, n_global)
+    csr = synth.build_lexical_csr(d_, t_, f_, n, v)
+    del d_, t_, f_
+    qt = mixed_lexical_queries(synth, nq, df, n_global)
+    g = synth.build_graph(n_global, lo, hi)
+    seeds = synth.graph_queries(nq, n_global, 3)
+    qtok = synth.query_tokens(nq)
+    idx = (T.GpuIndex(doc_base=lo).set_dense(x)
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf)
+           .set_tokens(synth.device_tokens(lo, n)))
+    res = idx.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    assert int(res.rescued) == 0
+    dn = CO.doc_norms(x)
+    Sd, Id = O.dense_topk_fast(x, q, 100, doc_id_base=lo, dnorm=dn)
+    Sl, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
+                         doc_id_base=lo)
+    Sg, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf, seeds, 2, n,
+                          50, chunk_base=lo)
+    assert_lists_equal(*res.channels["semantic"], Sd, Id, "dense")
+    assert_lists_equal(*res.channels["lexical"], Sl, Il, "bm25")
+    assert_lists_equal(*res.channels["graph"], Sg, Ig, "graph")
+    assert all(lo <= i < hi for row in Id for i in row)
+    Se, Ie, _ = CO.dense_topk_exact(x, q[:2], 100, doc_id_base=lo, dnorm=dn)
+    for j in range(2):
+        assert np.array_equal(Ie[j], Id[j]) and np.array_equal(Se[j], Sd[j])
+    ids, sc, cnt = res.ids.cpu().numpy(), res.scores.cpu().numpy(), res.counts.cpu().numpy()
+    for i in range(nq):
+        ei, es = O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 10)
+        assert list(ids[i, :cnt[i]]) == ei and list(sc[i, :cnt[i]]) == es, f"fused differs for query {i}"
+    # configs[4]: the shard's MaxSim scores of the fused top-100 and the reranked order
+    f100 = [O.fused_topk_ids(list(Il[i]), list(Id[i]), list(Ig[i]), 100)[0] for i in range(nq)]
+    width = max(len(f) for f in f100)
+    cand = np.full((nq, width), -1, dtype=np.int64)
+    for i, f in enumerate(f100):
+        cand[i, :len(f)] = f
+    got = idx.maxsim(dev(qtok), dev(cand)).cpu().numpy().astype(np.float64)
+    res4 = idx.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10, qtok=dev(qtok), rerank_top_k=100)
+    ids4 = res4.ids.cpu().numpy()
+    block = 8192
+    for i in range(0, nq, 6):   # the oracle's MaxSim on 8 queries: their candidates' token rows are
+        rows = {}               # regenerated block by block on the device and copied back to the host
+        for b in sorted({d // block for d in f100[i]}):   # (blocks are seeded by the GLOBAL block index)
+            blk = synth.device_tokens(b * block, block)
+            for d in f100[i]:
+                if d // block == b:
+                    rows[d] = blk[d - b * block].cpu().numpy()
+            del blk
+        dt = np.stack([rows[d] for d in f100[i]])
+        exp = CO.maxsim(qtok[i:i + 1], dt, np.arange(len(f100[i]), dtype=np.int64)[None])[0]
+        assert np.max(np.abs(got[i, :len(f100[i])] - exp)) < 1e-4
+        assert np.all(got[i, len(f100[i]):] == -np.inf)
+        order = O.rerank_order([float(np.float32(s)) for s in exp])[:10]
+        es = np.array([exp[p] for p in order])
+        for a in range(len(order)):   # identical wherever the oracle's scores are > 2e-4 apart
+            if (a == 0 or es[a - 1] - es[a] > 2e-4) and (a == len(order) - 1 or es[a] - es[a + 1] > 2e-4):
+                assert int(ids4[i][a]) == f100[i][order[a]]

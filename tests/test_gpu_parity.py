@@ -216,6 +216,33 @@ def test_dense_matches_reference_python_cosine(T, golden, shortlist):
         assert sorted(got) == sorted(ref_ids) or np.min(gaps[58:]) <= 1e-5
 
 
+def test_dense_f16_batch_limit_and_chunking(T, monkeypatch):
+    """The copy scan addresses candidate segments with 32-bit byte offsets: one call takes at
+    most thr_dense_f16_max_queries queries (a larger one is refused, not wrapped around), and
+    GpuIndex.dense_search splits larger batches -- same bits as the unsplit call."""
+    import ctypes as C
+    x, rng = rand_docs(30000, 768, 77)
+    q = rng.standard_normal((700, 768)).astype(np.float32)
+    idx = T.GpuIndex().set_dense(x, shortlist="f16")
+    lim = T._native.dense_f16_max_queries(768, True)
+    assert lim == 32512
+    lib = T._native.load()
+    qd = dev(q)
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    o = torch.empty(16, dtype=torch.int64, device="cuda")
+    rc = lib.thr_dense_topk_f16(idx.docs.data_ptr(), idx.docs16.data_ptr(), float(idx.doc_rel_err),
+                                idx.dnorm.data_ptr(), idx.inv_norm.data_ptr(), 30000, 768, 0, qd.data_ptr(),
+                                lim + 1, 10, 100, None, None, o.data_ptr(), o.data_ptr(), o.data_ptr(),
+                                o.data_ptr(), ws.data_ptr(), 1024, None)
+    assert rc == -2, rc   # THR_ERR_UNSUPPORTED, before anything is launched
+    S, I, cnt, nres = idx.dense_search(qd, 100)
+    monkeypatch.setattr(idx, "max_batch", lambda: 256)
+    S2, I2, cnt2, nres2 = idx.dense_search(qd, 100)
+    assert torch.equal(S, S2) and torch.equal(I, I2) and torch.equal(cnt, cnt2) and nres == nres2 == 0
+    S3, I3, cnt3, nres3 = idx.dense_search(qd, 100, sync=False)
+    assert torch.equal(I, I3) and int(nres3) == 0
+
+
 def test_dense_exact_path_alone(T):
     x, rng = rand_docs(20000, 256, 21)
     q = rng.standard_normal((9, 256)).astype(np.float32)
@@ -805,13 +832,15 @@ def test_full_size_1m_dense(T):
     # planted queries find their planted row first (cos ~ 0.894 vs ~0.19 for noise)
     assert np.all(S[::2, 0] > 0.8) and np.all(S[1::2, 0] < 0.4)
     sub = [0, 1, 2, 3, 64, 65, 126, 127]
-    Se, Ie, _ = CO.dense_topk_exact(x, q[sub], 100, dnorm=idx.dnorm.cpu().numpy())
+    dn = CO.doc_norms(x)   # the oracle's own norms (and thr_doc_norms equals them on all 1M rows)
+    assert np.array_equal(idx.dnorm.cpu().numpy(), dn)
+    Se, Ie, _ = CO.dense_topk_exact(x, q[sub], 100, dnorm=dn)
     for j, qi in enumerate(sub):
         assert np.array_equal(I[qi], Ie[j]) and np.array_equal(S[qi], Se[j])
-    # the bench batch (1536 queries = 16 tiles of 96 on the f16 copy scan): every shortlist
-    # flavour returns the same bits, and they are the oracle's fast path's
+    # a 1536-query batch (6 workgroup tiles of 256 queries on the f16 copy scan; the bench's is
+    # 2048): every shortlist flavour returns the same bits, and they are the oracle's fast path's
     qb = synth.dense_queries(1536, d, n)
-    Sf, If = O.dense_topk_fast(x, qb, 100, dnorm=idx.dnorm.cpu().numpy())
+    Sf, If = O.dense_topk_fast(x, qb, 100, dnorm=dn)
     Sf, If = np.stack(Sf), np.stack(If)
     for mode in ("f16", "f16-inline", "f32"):
         idx = T.GpuIndex().set_dense(x, shortlist=mode)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in thr_hip.h but not exported"
     assert sorted(T._native.EXPORTED_SYMBOLS) == names
-    assert lib.thr_abi_version() == T._native.ABI_VERSION == 4
+    assert lib.thr_abi_version() == T._native.ABI_VERSION == 5
     assert lib.thr_error_string(-3) == b"workspace too small"
 
 
@@ -33,9 +33,13 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
                               None, None, None, 0, None) == -1
     # bm25: a vocabulary size is part of the call (term ids >= V are ignored, not dereferenced)
     assert lib.thr_bm25_topk(None, None, None, None, None, None, None, 1.0, 1.2, 0.75, 10, 5, 0, None,
-                             1, 4, 10, 0, None, None, None, None, None, None) == -1
+                             1, 4, 10, 0, None, None, None, None, None, None, 0, None) == -1
+    # the work decomposition's item list, slice edges and per-slice lists: grows with nq, terms, k
+    assert lib.thr_bm25_workspace_bytes(2048, 4, 50) > (2048 + 8192) * 50 * 16
+    assert lib.thr_bm25_workspace_bytes(2048, 32, 50) > lib.thr_bm25_workspace_bytes(2048, 4, 50)
+    assert lib.thr_bm25_workspace_bytes(0, 4, 50) == 0
     assert lib.thr_bm25_block_count(129) == 2 and lib.thr_bm25_block_count(0) == 0
-    assert lib.thr_graph_workspace_bytes(2, 1000) == 2 * 8192 * 8 + 16 * 1024
+    assert lib.thr_graph_workspace_bytes(2, 1000) == 2 * 8192 * 8 + 64 * 1024
     assert lib.thr_dense_workspace_bytes(1_000_000, 768, 1024, 128) > 2 ** 20
     assert lib.thr_maxsim(None, 1, 32, None, 1, 128, 128, None, 1, None, 0, None) == -1
     assert lib.thr_rrf_fuse(None, 0, None, 0, None, 0, 1, 0.7, 0.8, 1.0, 60, 10, None, None, None,
@@ -54,6 +58,10 @@ def test_host_side_planning_functions():
     assert N.dense_f16_query_tile(768, False, 1536) == 64     # in-flight rounding: transpose tiles
     assert N.dense_f16_query_tile(1024, False, 1536) == 32
     assert N.dense_f16_query_tile(640, True, 64) == 0         # no f16 kernel at that dim
+    # the copy scan's candidate-segment offsets are 32 bits: 131072 bytes per query, whole tiles
+    assert N.dense_f16_max_queries(768, True) == 32512 and N.dense_f16_max_queries(1024, True) == 32640
+    assert N.dense_f16_max_queries(768, True) * 131072 < 2 ** 32
+    assert N.dense_f16_max_queries(768, False) == 2 ** 31 - 1
     lib = N.load()
     assert lib.thr_dense_f16_copy_bytes(33, 768) == 64 * 768 * 2   # rows padded to tiles of 32
     assert lib.thr_dense_rescue_workspace_bytes(1024, 100) == 1024 * 64 * 100 * 16

@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -54,14 +54,16 @@ _SIGNATURES = {
     "thr_dense_f16_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32]),
     "thr_dense_f16_copy_bytes": (_sz, [_i64, _i32]),
     "thr_dense_f16_query_tile": (_i32, [_i32, _i32, _i32]),
+    "thr_dense_f16_max_queries": (_i32, [_i32, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_bm25_block_count": (_sz, [_i64]),
     "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp]),
+    "thr_bm25_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64,
-                             _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32,
                               _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -248,6 +250,11 @@ def dense_f16_query_tile(dim: int, packed: bool, n_queries: int) -> int:
     return int(load().thr_dense_f16_query_tile(dim, 1 if packed else 0, n_queries))
 
 
+def dense_f16_max_queries(dim: int, packed: bool) -> int:
+    """Largest batch of one thr_dense_topk_f16 call (32-bit candidate-segment offsets)."""
+    return int(load().thr_dense_f16_max_queries(dim, 1 if packed else 0))
+
+
 def dense_rescue_workspace_bytes(n_queries: int, k: int) -> int:
     return int(load().thr_dense_rescue_workspace_bytes(n_queries, k))
 
@@ -372,9 +379,17 @@ def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float 
     return tub, bub
 
 
+def bm25_workspace_bytes(n_queries: int, max_terms: int, k: int) -> int:
+    return int(load().thr_bm25_workspace_bytes(n_queries, max_terms, k))
+
+
 def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms, k: int,
               id_base: int = 0, k1: float = 1.2, b: float = 0.75, bounds=None,
-              conjunctive: bool = False, doc_coll=None, query_coll=None):
+              conjunctive: bool = False, doc_coll=None, query_coll=None,
+              workspace: Optional[torch.Tensor] = None):
+    """``workspace``: a uint8 device tensor of >= bm25_workspace_bytes(nq, max_terms, k) bytes
+    (item list, slice edges and per-slice lists of the work decomposition); allocated when
+    missing or too small."""
     pr = _dev(rowptr, torch.int64, "rowptr", 1)
     pdoc = _dev(post_doc, torch.int32, "post_doc", 1)
     ptf = _dev(post_tf, torch.int32, "post_tf", 1)
@@ -399,9 +414,14 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
         if doc_coll.shape[0] != doclen.shape[0] or query_coll.shape[0] != nq:
             raise NativeError("bm25: doc_coll / query_coll have the wrong length")
     S, I, cnt, _ = _alloc_out(nq, k, rowptr.device)
+    need = bm25_workspace_bytes(nq, mt, k)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=rowptr.device)
+    pw = _dev(workspace, workspace.dtype, "workspace")
     _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, avgdl, k1, b, doclen.shape[0],
                                 idf.shape[0], id_base, pqt, nq, mt, k, 1 if conjunctive else 0, pdc,
-                                pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), _stream()),
+                                pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), pw,
+                                workspace.numel() * workspace.element_size(), _stream()),
            "thr_bm25_topk")
     return S, I, cnt
 

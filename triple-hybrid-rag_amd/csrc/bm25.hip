@@ -7,7 +7,15 @@
 // the oracle's (oracle/thr_oracle.py bm25_scores): OR semantics, float64,
 // contributions added in query-term order, every operation one IEEE rounding.
 //
-// One workgroup per query.  Posting lists are doc-sorted, so a doc's score is
+// Work decomposition: a query whose lists hold more than BM_SPLIT_MIN postings is cut
+// into DOC-RANGE slices of ~equal posting counts (the slice edges are docs of its longest
+// list), one work item per slice; short queries are one item.  A persistent grid of
+// workgroups pulls items from a device-side counter, so a stop-word query of millions of
+// postings is the job of up to 128 workgroups instead of one; the slices of a query share
+// the pruning threshold through a global atomic max and a last kernel merges their lists.
+// (thr_bm25_plan_kernel / bm25_edges_kernel / bm25_topk_kernel / bm25_merge_kernel.)
+//
+// Inside an item the posting lists are doc-sorted, so a doc's score is
 // assembled by its OWNER posting -- the posting of the first query term that
 // contains the doc.  That gives the fixed summation order with no atomics and
 // no hash table.  The doc ids are staged in LDS (posting-block staging, in
@@ -99,427 +107,709 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
     }
 }
 
-// The query's postings are consumed in DOC-RANGE passes.  A pass stages, from every term's list,
+// ---------------------------------------------------------------------------------------------
+// Work decomposition (one launch each, no host round trip):
+//   bm25_plan_kernel   per query: the valid term ids in query order, the total posting count,
+//                      the number of doc-range slices S_q (1 below BM_SPLIT_MIN postings, else
+//                      ~total / target, <= BM_MAX_SLICES; the target doubles until all items
+//                      fit the item list), the item list (query, slice);
+//   bm25_edges_kernel  per (item, term): the first posting of the slice in the term's list
+//                      (slice s of S starts at doc B_s = the (len * s / S)-th doc of the
+//                      query's longest list: equal shares of the dominant list whatever the
+//                      distribution of its docs; the other lists are cut by binary search);
+//   bm25_topk_kernel   persistent workgroups pull items from ctl[1];
+//   bm25_merge_kernel  per query with S_q > 1: the best k of its slices' lists.
+constexpr int BM_MAX_SLICES = 128;
+constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = n_queries + this
+constexpr int BM_SPLIT_MIN = 24576;    // postings: shorter queries are one work item (<= 3 passes)
+constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at (before doubling)
+constexpr int PLAN_THREADS = 1024;
+
+__device__ __forceinline__ int bm_slices(long long tot, long long target) {
+    if (tot < BM_SPLIT_MIN) return 1;
+    const long long s = (tot + target - 1) / target;
+    return s < 1 ? 1 : s > BM_MAX_SLICES ? BM_MAX_SLICES : (int)s;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
+    const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
+    int nq, int mt, int cap, int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot,
+    int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
+    int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
+    __shared__ int red[PLAN_THREADS];
+    const int per = (nq + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int q0 = threadIdx.x * per;
+    const int q1 = q0 + per < nq ? q0 + per : nq;
+    for (int q = q0; q < q1; ++q) {
+        int nt = 0, lng = 0;
+        long long tot = 0, best = -1;
+        for (int j = 0; j < mt; ++j) {
+            const int term = query_terms[(int64_t)q * mt + j];
+            if (term < 0 || term >= n_vocab) continue;   // padding / unknown term: no postings
+            const long long len = rowptr[term + 1] - rowptr[term];
+            if (len > best) { best = len; lng = nt; }
+            q_terms[(int64_t)q * mt + nt++] = term;
+            tot += len;
+        }
+        q_nt[q] = nt;
+        q_long[q] = lng;
+        q_tot[q] = tot;
+    }
+    long long target = BM_TARGET0;
+    int total = 0, mine = 0;
+    for (;;) {
+        mine = 0;
+        for (int q = q0; q < q1; ++q) mine += bm_slices(q_tot[q], target);
+        red[threadIdx.x] = mine;
+        __syncthreads();
+        for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        total = red[0];
+        __syncthreads();
+        if (total <= cap) break;   // (every query is one item once target >= its total: terminates)
+        target *= 2;
+    }
+    // exclusive prefix of the per-thread item counts
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < PLAN_THREADS; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? red[threadIdx.x - o] : 0;
+        __syncthreads();
+        red[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int base = red[threadIdx.x] - mine;
+    for (int q = q0; q < q1; ++q) {
+        const int S = bm_slices(q_tot[q], target);
+        q_S[q] = S;
+        q_item0[q] = base;
+        for (int s = 0; s < S; ++s) items[base + s] = make_int2(q, s);
+        base += S;
+    }
+    if (threadIdx.x == 0) ctl[0] = total;
+}
+
+__global__ __launch_bounds__(256) void bm25_edges_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
+    const int32_t* __restrict__ ctl, const int32_t* __restrict__ q_nt,
+    const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
+    const int32_t* __restrict__ q_terms, const int2* __restrict__ items, int mt,
+    int32_t* __restrict__ ipos) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int item = (int)(g / mt), slot = (int)(g % mt);
+    if (item >= ctl[0]) return;
+    const int2 it = items[item];
+    const int q = it.x, s = it.y;
+    if (slot >= q_nt[q]) return;
+    int pos = 0;
+    if (s > 0) {
+        const int S = q_S[q], L = q_long[q];
+        const int tl = q_terms[(int64_t)q * mt + L];
+        const int64_t lo_l = rowptr[tl], len_l = rowptr[tl + 1] - lo_l;
+        const int64_t p = len_l * s / S;   // (S > 1 only with >= BM_SPLIT_MIN postings: len_l > S)
+        if (slot == L) {
+            pos = (int)p;
+        } else {
+            const int term = q_terms[(int64_t)q * mt + slot];
+            const int64_t lo = rowptr[term];
+            pos = count_below(post_doc + lo, (int)(rowptr[term + 1] - lo), (int64_t)post_doc[lo_l + p]);
+        }
+    }
+    ipos[(int64_t)item * mt + slot] = pos;
+}
+
+// An item's postings are consumed in DOC-RANGE passes.  A pass stages, from every term's list,
 // the next quota_t postings (quotas proportional to what is left of each list, together one LDS
 // stage), then takes d_hi = the smallest "last staged doc + 1" among the lists that have more
 // postings behind their quota: every posting with doc < d_hi of EVERY list is then on chip, so a
 // doc's postings all fall into the same pass and the owner search never leaves LDS, whatever
-// the length of the lists.  (No search in global memory picks the range: round 1 did that with
-// a chain of ~20 dependent loads per term and pass, the dominant cost on long lists.)  The
-// postings with doc >= d_hi stay for the next pass and are staged again.
+// the length of the lists.  The postings with doc >= d_hi stay for the next pass and are staged
+// again.
 //
 // WAND-style pruning (exact): passes visit the docs in ascending id order, so once k docs have
-// been scored every later doc has to BEAT the current k-th best score theta (a tie loses on the
-// id).  Phase 1 of a pass is LDS-only: an owner posting (the posting of the first query term
-// that holds its doc) learns from the staged doc ids which query terms hold the doc and sums
+// been scored every later doc of the item has to BEAT the item's k-th best score theta (a tie
+// loses on the id); against the threshold shared by the query's other slices (th_glob, whose
+// docs may have larger ids) a doc is dropped only when its bound is strictly BELOW it.  Phase 1
+// of a pass is LDS-only: it learns from the staged doc ids which query terms hold a doc and sums
 // their term_ub in query-term order; rounding is monotone, so fl(sum of bounds) >= fl(sum of
-// contributions), and a doc whose bound does not exceed theta is dropped there.  The survivors
-// are compacted into an LDS list; phase 2 walks that list 512 at a time: tighter block_ub check,
-// collection filter, term-frequency / doc-length gathers, float64 score, top-k push.  theta is
-// refreshed at the end of a pass when enough new docs have entered the buffer.
+// contributions).  The survivors are compacted into an LDS list; phase 2 walks that list a
+// workgroup's width at a time: tighter block_ub check, collection filter, term-frequency /
+// doc-length gathers, float64 score, top-k push.
+//
+// Phase 1 has three forms.  DENSE lists: every staged posting ORs its term's bit into the
+// doc's slot of a mask array -- O(1) per posting -- and the non-empty slots are the candidate
+// docs.  The mask holds 8 bits per doc for queries of <= 8 terms (4 BM_WINDOW docs), 32 bits
+// otherwise; a pass whose staged range is wider than the mask is CUT to the mask's width when
+// that still consumes at least an eighth of the staged postings (so stop-word lists always
+// take this path).  SPARSE lists: a Bloom bit per (list, doc) answers "is this doc in another
+// list" with one LDS read; singletons are scored (or dropped on term_ub) at once, the others
+// are searched from a dense work list.  In between, with a threshold: owners and bounds by
+// binary search in LDS.
 template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP>
 __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
     const double* __restrict__ idf, const double* __restrict__ term_ub,
-    const double* __restrict__ block_ub, double avgdl, double k1, double b, int64_t n_docs,
-    int64_t n_vocab, int64_t id_base, const int32_t* __restrict__ query_terms, int max_terms, int k,
-    int conjunctive, const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
+    const double* __restrict__ block_ub, double avgdl, double k1, double b, int64_t id_base,
+    int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
+    const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S,
+    const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
+    const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
+    double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
     __shared__ TermRange tr[THR_BM25_MAX_TERMS];   // .sub = postings of this pass, .lds_off = where staged
     __shared__ double t_idf[THR_BM25_MAX_TERMS], t_ub[THR_BM25_MAX_TERMS];
     __shared__ int t_staged[THR_BM25_MAX_TERMS];   // postings of the term staged in this pass
+    __shared__ int t_subwin[THR_BM25_MAX_TERMS];   // ... of them inside the mask window
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
-    __shared__ int n_terms, remaining, last_compact, n_surv;
-    __shared__ int64_t d_hi, d_lo;
+    __shared__ int remaining, last_compact, n_surv, cur_item;
+    __shared__ int64_t d_hi, d_lo, p_last;
+    __shared__ double th_glob;
     __shared__ double b_s[BM_CAP];
     __shared__ int64_t b_id[BM_CAP];
     __shared__ int b_cnt;
     __shared__ double th_s;
     __shared__ int64_t th_id;
     __shared__ int32_t st_doc[BM_STAGE];
-    // mask path: mask[BM_WINDOW] (which query terms hold doc d_lo + slot) + up to BM_WINDOW surviving
-    // slots behind it; search path: up to BM_STAGE surviving staged indices.  One 24 KiB buffer.
+    // mask path: BM_WINDOW mask words (which query terms hold doc d_lo + slot; 1 or 4 slots per
+    // word) + up to BM_WINDOW surviving slots behind them; search path: up to BM_STAGE surviving
+    // staged indices; Bloom path: the bits + a work list.  One 24 KiB buffer.
     __shared__ uint32_t scratch[BM_WINDOW + BM_WINDOW / 2];
     static_assert(sizeof(uint32_t) * (BM_WINDOW + BM_WINDOW / 2) >= sizeof(uint16_t) * BM_STAGE, "survivor list must fit");
     static_assert(BM_CAP >= THR_TOPK_MAX + BM_THREADS && BM_STAGE <= 65536, "top-k buffer / 16-bit staged indices");
+    static_assert(4 * BM_WINDOW <= 65536, "16-bit slot indices");
     uint32_t* mask = scratch;
 
-    const int q = blockIdx.x;
-    const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
-    // set-up, one thread per query term: valid terms keep their query order (a ballot prefix)
-    {
-        int term = -1;
-        if (threadIdx.x < max_terms) {
-            term = query_terms[(int64_t)q * max_terms + threadIdx.x];
-            if (term >= n_vocab) term = -1;   // unknown term: no postings
-        }
-        const uint64_t m = __ballot(term >= 0);   // (max_terms <= 32: all in wave 0)
-        if (threadIdx.x < max_terms && term >= 0) {
-            const int slot = __popcll(m & ((1ull << threadIdx.x) - 1ull));
-            const int64_t lo = rowptr[term], hi = rowptr[term + 1];
-            tr[slot].lo = lo;
-            tr[slot].len = (int)(hi - lo);
+    const int n_items = ctl[0];
+    BlockTopK<BM_CAP, BM_THREADS> tk;
+    for (;;) {
+        __syncthreads();   // the previous item's LDS state is no longer read
+        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[1], 1);
+        __syncthreads();
+        const int item = cur_item;
+        if (item >= n_items) break;   // (uniform: every workgroup of the grid ends here)
+        const int2 it = items[item];
+        const int q = it.x, sl = it.y;
+        const int S = q_S[q];
+        const int nt = q_nt[q];
+        const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
+        // 8 mask bits per doc for queries of <= 8 terms: 4 docs per mask word
+        const int ms = nt <= 8 ? 2 : 0;
+        const int spw = 1 << ms;
+        const int64_t WIN = (int64_t)BM_WINDOW << ms;
+        if ((int)threadIdx.x < nt) {
+            const int slot = threadIdx.x;
+            const int term = q_terms[(int64_t)q * max_terms + slot];
+            const int64_t lo = rowptr[term];
+            const int full = (int)(rowptr[term + 1] - lo);
+            const int start = ipos[(int64_t)item * max_terms + slot];
+            const int end = sl == S - 1 ? full : ipos[(int64_t)(item + 1) * max_terms + slot];
+            tr[slot].lo = lo + start;
+            tr[slot].len = end - start;
             tr[slot].cur = 0;
             t_idf[slot] = idf[term];
             t_ub[slot] = term_ub ? term_ub[term] : INFINITY;
         }
         if (threadIdx.x == 0) {
-            n_terms = __popcll(m);
             last_compact = 0;
+            th_glob = -INFINITY;
         }
-    }
-    BlockTopK<BM_CAP, BM_THREADS> tk;
-    tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
-    const int nt = n_terms;
-    if (threadIdx.x == 0) {
-        int total = 0;
-        for (int t = 0; t < nt; ++t) total += tr[t].len;
-        remaining = total;
-    }
-    __syncthreads();
-
-    while (remaining > 0) {
-        // ---- quotas: the stage is shared out in proportion to what is left of each list ----
-        if (threadIdx.x == 0) {
-            int off = 0;
-            const int spare = BM_STAGE - 32 * nt;   // every list gets at least 32 slots
-            for (int t = 0; t < nt; ++t) {
-                const int rem = tr[t].len - tr[t].cur;
-                int quota = 32 + (int)((int64_t)spare * rem / remaining);
-                quota = quota < rem ? quota : rem;
-                tr[t].lds_off = off;
-                t_staged[t] = quota;
-                off += quota;
-            }
-            d_hi = INT64_MAX;
-            d_lo = INT64_MAX;
-        }
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            const int32_t* src = post_doc + tr[t].lo + tr[t].cur;
-            int32_t* dst = st_doc + tr[t].lds_off;
-            for (int i = threadIdx.x; i < t_staged[t]; i += BM_THREADS) dst[i] = src[i];
-        }
-        __syncthreads();
-        if (threadIdx.x < nt) {
-            const int t = threadIdx.x;
-            if (t_staged[t] > 0 && tr[t].cur + t_staged[t] < tr[t].len)   // more postings behind the quota
-                atomicMin((unsigned long long*)&d_hi,
-                          (unsigned long long)((int64_t)st_doc[tr[t].lds_off + t_staged[t] - 1] + 1));
-            if (t_staged[t] > 0)
-                atomicMin((unsigned long long*)&d_lo, (unsigned long long)st_doc[tr[t].lds_off]);
-        }
-        __syncthreads();
-        if (threadIdx.x < nt) {
-            TermRange& r = tr[threadIdx.x];
-            r.sub = d_hi == INT64_MAX ? t_staged[threadIdx.x]
-                                      : count_below(st_doc + r.lds_off, t_staged[threadIdx.x], d_hi);
-        }
-        if (threadIdx.x == 0) n_surv = 0;
-        __syncthreads();
+        tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
         if (threadIdx.x == 0) {
             int total = 0;
-            for (int t = 0; t < nt; ++t) {
-                t_prefix[t] = total;
-                total += tr[t].sub;
-            }
-            t_prefix[nt] = total;
+            for (int t = 0; t < nt; ++t) total += tr[t].len;
+            remaining = total;
         }
         __syncthreads();
-        const int total = t_prefix[nt];
-        const bool have_theta = b_cnt >= k && th_s > -INFINITY;
-        const double theta = th_s;
 
-        // ---- phase 1 (LDS only): owners, which terms hold the doc, bound against theta ----
-        // Dense lists give narrow doc ranges: when the pass's docs fit BM_WINDOW slots, every
-        // staged posting ORs its term's bit into the doc's slot -- O(1) per posting instead of a
-        // binary search per (posting, other term) -- and the slots are then the candidate docs
-        // (owner = lowest bit).  Wide ranges (sparse lists, few postings) keep the searches.
-        int64_t last = d_hi;   // one past the last doc of the pass
-        if (d_hi == INT64_MAX) {
-            last = 0;
-            for (int t = 0; t < nt; ++t)
-                if (tr[t].sub > 0) {
-                    const int64_t e = (int64_t)st_doc[tr[t].lds_off + tr[t].sub - 1] + 1;
-                    last = e > last ? e : last;
+        while (remaining > 0) {
+            // ---- quotas: the stage is shared out in proportion to what is left of each list ----
+            if (threadIdx.x == 0) {
+                const unsigned long long g = S > 1 ? __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED,
+                                                                       __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                th_glob = g ? dkey_inv(g) : -INFINITY;
+                // no threshold anywhere yet and a long way to go: a short first pass gets one cheaply
+                // (without a threshold every staged doc is scored in full)
+                const bool warm = g != 0ull || (b_cnt >= k && th_s > -INFINITY) || remaining <= BM_STAGE;
+                const int stage = warm ? BM_STAGE : BM_STAGE / 4;
+                int off = 0;
+                const int spare = stage - 32 * nt;   // every list gets at least 32 slots
+                for (int t = 0; t < nt; ++t) {
+                    const int rem = tr[t].len - tr[t].cur;
+                    int quota = 32 + (int)((int64_t)spare * rem / remaining);
+                    quota = quota < rem ? quota : rem;
+                    tr[t].lds_off = off;
+                    t_staged[t] = quota;
+                    off += quota;
                 }
-        }
-        const int64_t first = d_lo;
-        const bool masked = total > 0 && last - first <= BM_WINDOW;
-        uint16_t* surv = masked ? reinterpret_cast<uint16_t*>(scratch + BM_WINDOW) : reinterpret_cast<uint16_t*>(scratch);
-        if (masked) {
-            const int w = (int)(last - first);
-            for (int i = threadIdx.x; i < w; i += BM_THREADS) mask[i] = 0u;
-            __syncthreads();
-            for (int i = threadIdx.x; i < total; i += BM_THREADS) {
-                int t = 0;
-                while (i >= t_prefix[t + 1]) ++t;
-                const int32_t d = st_doc[tr[t].lds_off + (i - t_prefix[t])];
-                atomicOr(&mask[d - first], 1u << t);
+                d_hi = INT64_MAX;
+                d_lo = INT64_MAX;
             }
             __syncthreads();
-            for (int slot = threadIdx.x; slot < w; slot += BM_THREADS) {
-                uint32_t m = mask[slot];
-                if (!m) continue;
-                if (conjunctive && __popc(m) < nt) continue;
-                if (have_theta) {
-                    double ub = 0.0;
-                    for (uint32_t r = m; r; r &= r - 1) ub = __dadd_rn(ub, t_ub[__ffs((int)r) - 1]);
-                    if (!(ub > theta)) continue;
-                }
-                surv[atomicAdd(&n_surv, 1)] = (uint16_t)slot;
+            for (int t = 0; t < nt; ++t) {
+                const int32_t* src = post_doc + tr[t].lo + tr[t].cur;
+                int32_t* dst = st_doc + tr[t].lds_off;
+                for (int i = threadIdx.x; i < t_staged[t]; i += BM_THREADS) dst[i] = src[i];
             }
-        } else if (have_theta && (last - first) < 32 * (int64_t)total) {
-            // moderately dense lists and a threshold to prune with: LDS-only owner / bound search,
-            // survivors to phase 2 (a doc is dropped on the sum of its terms' bounds before any
-            // gather; the sweep below would find most docs shared and score them all)
-            for (int i = threadIdx.x; i < total; i += BM_THREADS) {
-                int t = 0;
-                while (i >= t_prefix[t + 1]) ++t;
-                const int off = i - t_prefix[t];
-                const int32_t d = st_doc[tr[t].lds_off + off];
-                bool owner = true;
-                for (int e = 0; e < t && owner; ++e)
-                    if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
-                if (!owner) continue;
-                int present = 1;
-                double ub = __dadd_rn(0.0, t_ub[t]);
-                for (int e = t + 1; e < nt; ++e)
-                    if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) {
-                        ++present;
-                        ub = __dadd_rn(ub, t_ub[e]);
+            __syncthreads();
+            if ((int)threadIdx.x < nt) {
+                const int t = threadIdx.x;
+                if (t_staged[t] > 0 && tr[t].cur + t_staged[t] < tr[t].len)   // more postings behind the quota
+                    atomicMin((unsigned long long*)&d_hi,
+                              (unsigned long long)((int64_t)st_doc[tr[t].lds_off + t_staged[t] - 1] + 1));
+                if (t_staged[t] > 0)
+                    atomicMin((unsigned long long*)&d_lo, (unsigned long long)st_doc[tr[t].lds_off]);
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < nt) {
+                TermRange& r = tr[threadIdx.x];
+                const int stg = t_staged[threadIdx.x];
+                r.sub = d_hi == INT64_MAX ? stg : count_below(st_doc + r.lds_off, stg, d_hi);
+                const int64_t dw = d_lo + WIN < d_hi ? d_lo + WIN : d_hi;
+                t_subwin[threadIdx.x] = dw == INT64_MAX ? stg : count_below(st_doc + r.lds_off, stg, dw);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int total = 0, totw = 0;
+                int64_t last = 0;
+                for (int t = 0; t < nt; ++t) {
+                    total += tr[t].sub;
+                    totw += t_subwin[t];
+                    if (tr[t].sub > 0) {
+                        const int64_t e = (int64_t)st_doc[tr[t].lds_off + tr[t].sub - 1] + 1;
+                        last = e > last ? e : last;
                     }
-                if (conjunctive && present < nt) continue;
-                if (!(ub > theta)) continue;
-                surv[atomicAdd(&n_surv, 1)] = (uint16_t)(tr[t].lds_off + off);
-            }
-        } else {
-            // sparse lists (or no threshold yet): every owner is scored in the same sweep that finds it.
-            // Sparse lists share few docs, so nearly every "is this doc in list e" question is
-            // answered NO: a Bloom bit per (list, doc hash) in the idle scratch buffer answers
-            // those with one LDS read instead of a binary search (a chain of ~11); a set bit is
-            // confirmed by the search, so the result is exact.  The doc-length and own-tf gathers
-            // of the NEXT sweep step are requested before the current one is worked on.
-            // bits per list: the largest power of two (<= 32768) that fits the buffer nt times next
-            // to a work list that could take every posting of the pass (16 bits each)
-            constexpr int SCR_WORDS = BM_WINDOW + BM_WINDOW / 2;
-            int bwords = 1024;
-            while (bwords >= 128 && nt * bwords + (total + 1) / 2 > SCR_WORDS) bwords >>= 1;
-            const bool bloom = bwords >= 128;
-            const int bl2 = 31 - __clz(bwords * 32);
-            if (bloom) {
-                for (int i = threadIdx.x; i < nt * bwords; i += BM_THREADS) scratch[i] = 0u;
-                __syncthreads();
-                for (int i = threadIdx.x; i < total; i += BM_THREADS) {
-                    int t = 0;
-                    while (i >= t_prefix[t + 1]) ++t;
-                    const uint32_t h = ((uint32_t)st_doc[tr[t].lds_off + (i - t_prefix[t])] * 2654435761u) >> (32 - bl2);
-                    atomicOr(&scratch[t * bwords + (h >> 5)], 1u << (h & 31));
                 }
-                __syncthreads();
-            }
-            auto lookup = [&](int e, int32_t d) -> int {   // index of d in list e's staged ids, or -1
-                if (bloom) {
-                    const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
-                    if (!((scratch[e * bwords + (h >> 5)] >> (h & 31)) & 1u)) return -1;
-                }
-                return find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-            };
-            // the searching version of "score posting (t, off) if it owns doc d"
-            auto score_full = [&](int t, int off, int32_t d, float dl_own, int32_t tf_own, double& score) -> bool {
-                for (int e = 0; e < t; ++e)
-                    if (lookup(e, d) >= 0) return false;
-                int present = 0;
-                int64_t where[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    where[e] = -1;
-                    if (e >= t && e < nt) {
-                        const int f = e == t ? off : lookup(e, d);
-                        if (f >= 0) {
-                            where[e] = tr[e].lo + tr[e].cur + f;
-                            ++present;
+                // wider than the mask, but the mask's width holds a fair share of the staged
+                // postings: cut the pass to that width (the rest is staged again)
+                if (total > 0 && last - d_lo > WIN && (int64_t)totw * 8 >= total) {
+                    total = 0;
+                    last = 0;
+                    for (int t = 0; t < nt; ++t) {
+                        tr[t].sub = t_subwin[t];
+                        total += tr[t].sub;
+                        if (tr[t].sub > 0) {
+                            const int64_t e = (int64_t)st_doc[tr[t].lds_off + tr[t].sub - 1] + 1;
+                            last = e > last ? e : last;
                         }
                     }
                 }
-                auto far = [&](int e) -> int64_t {   // terms beyond the 8th: searched when needed
-                    const int f = e < t ? -1 : (e == t ? off : lookup(e, d));
-                    return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
-                };
-                for (int e = 8; e < nt; ++e) present += far(e) >= 0 ? 1 : 0;
-                if (conjunctive && present < nt) return false;
-                if (qc != -1 && doc_coll[d] != qc) return false;
-                const double dl = (double)dl_own;
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (where[e] >= 0)
-                        score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)(e == t ? tf_own : post_tf[where[e]]), dl, avgdl, k1, b));
-                for (int e = 8; e < nt; ++e) {
-                    const int64_t w = far(e);
-                    if (w >= 0)
-                        score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)(e == t ? tf_own : post_tf[w]), dl, avgdl, k1, b));
-                }
-                return true;
-            };
-            int n_t = 0, n_off = 0;
-            int32_t n_d = 0, n_tf = 0;
-            float n_dl = 0.f;
-            auto fetch = [&](int i) {
-                if (i >= 0 && i < total) {
-                    n_t = 0;
-                    while (i >= t_prefix[n_t + 1]) ++n_t;
-                    n_off = i - t_prefix[n_t];
-                    n_d = st_doc[tr[n_t].lds_off + n_off];
-                    n_dl = doclen[n_d];
-                    n_tf = post_tf[tr[n_t].lo + tr[n_t].cur + n_off];
-                }
-            };
-            // With the filter, sweep 1 never searches: a posting whose doc shows in no other list's
-            // bits is the doc's only posting (owner, one contribution) and is scored at once; the
-            // few with a set bit -- which a wave would otherwise wait for, lane by lane -- go to a
-            // work list (behind the bits in the same buffer) that sweep 2 walks densely.
-            static_assert(2 * (BM_WINDOW + BM_WINDOW / 2) >= BM_STAGE, "work list of a pass without the filter");
-            uint16_t* work = reinterpret_cast<uint16_t*>(bloom ? scratch + nt * bwords : scratch);
-            if (threadIdx.x == 0) n_surv = 0;   // (work list length; phase 2 below sees 0 again)
-            __syncthreads();
-            if (bloom) {
-                // list by list: everything that depends on the term is uniform (scalar registers)
+                int acc = 0;
                 for (int t = 0; t < nt; ++t) {
-                    const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
-                    const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
-                    const int pre = __builtin_amdgcn_readfirstlane(t_prefix[t]);
-                    const int32_t* tf_t = post_tf + tr[t].lo + tr[t].cur;
-                    const double idf_t = t_idf[t], ub_t = t_ub[t];
-                    const bool single_ok = !(conjunctive && nt > 1);
-                    for (int base = 0; base < sub; base += BM_THREADS) {
-                        const int i = base + (int)threadIdx.x;
-                        bool owner = false;
-                        double score = 0.0;
-                        int32_t d = 0;
-                        if (i < sub) {
-                            d = st_doc[off0 + i];
-                            const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
-                            const uint32_t w = h >> 5, bit = 1u << (h & 31);
-                            bool alone = true;
-                            for (int e = 0; e < nt; ++e)
-                                if (e != t && (scratch[e * bwords + w] & bit)) alone = false;
-                            if (!alone) {
-                                work[atomicAdd(&n_surv, 1)] = (uint16_t)(pre + i);
-                            } else if (single_ok && !(ub_t < th_s) && !(qc != -1 && doc_coll[d] != qc)) {
-                                // (ub_t < threshold: no posting of this list can enter on its own)
-                                owner = true;
-                                score = __dadd_rn(score, bm25_contrib(idf_t, (double)tf_t[i], (double)doclen[d], avgdl, k1, b));
+                    t_prefix[t] = acc;
+                    acc += tr[t].sub;
+                }
+                t_prefix[nt] = acc;
+                p_last = last;   // one past the last doc of the pass
+                n_surv = 0;
+            }
+            __syncthreads();
+            const int total = t_prefix[nt];
+            const double thg = th_glob;                 // the query's other slices' threshold (or -inf)
+            const bool have_local = b_cnt >= k && th_s > -INFINITY;
+            const double theta = have_local ? th_s : -INFINITY;
+            const bool have_theta = have_local || thg > -INFINITY;
+            // (a bound ub cannot make the top-k: it does not beat this item's threshold, or it is
+            // below the threshold of the query's other slices)
+            auto pruned = [&](double ub) -> bool { return !(ub > theta) || ub < thg; };
+            auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
+            const int64_t last = p_last;
+            const int64_t first = d_lo;
+            const bool masked = total > 0 && last - first <= WIN;
+            uint16_t* surv = masked ? reinterpret_cast<uint16_t*>(scratch + BM_WINDOW) : reinterpret_cast<uint16_t*>(scratch);
+            auto slot_mask = [&](int slot) -> uint32_t {
+                const uint32_t v = mask[slot >> ms];
+                return ms ? (v >> ((slot & 3) << 3)) & 0xFFu : v;
+            };
+
+            // ---- phase 2: the survivors, densely ----
+            auto phase2 = [&](bool from_mask, int ns) {
+                for (int base = 0; base < ns; base += BM_THREADS) {
+                    const int j = base + threadIdx.x;
+                    bool keep = j < ns;
+                    double score = 0.0;
+                    int32_t d = 0;
+                    if (keep) {
+                        int t = 0, at;
+                        uint32_t has = 0xFFFFFFFFu;   // terms that may hold the doc
+                        if (from_mask) {   // survivor = doc slot: owner = lowest term bit, position searched
+                            d = (int32_t)(first + surv[j]);
+                            has = slot_mask(surv[j]);
+                            t = __ffs((int)has) - 1;
+                            at = tr[t].lds_off + find_doc(st_doc + tr[t].lds_off, tr[t].sub, d);
+                        } else {        // survivor = staged index of the owner posting
+                            at = surv[j];
+                            while (t + 1 < nt && at >= tr[t + 1].lds_off) ++t;   // lds_off ascends with t
+                            d = st_doc[at];
+                        }
+                        // staged position of the doc in every term that holds it (first 8 terms in
+                        // registers -- static indexing only --, the rest searched again when needed)
+                        int wf[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            wf[e] = -1;
+                            if (e >= t && e < nt && ((has >> e) & 1u))
+                                wf[e] = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                        }
+                        auto where_far = [&](int e) -> int64_t {   // e >= 8
+                            if (!((has >> e) & 1u)) return -1;
+                            const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                            return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
+                        };
+                        if (have_theta && block_ub) {
+                            double ub2 = 0.0;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (wf[e] >= 0) ub2 = __dadd_rn(ub2, block_ub[(tr[e].lo + tr[e].cur + wf[e]) / BM_BLOCK]);
+                            for (int e = 8 > t ? 8 : t; e < nt; ++e) {
+                                const int64_t w = where_far(e);
+                                if (w >= 0) ub2 = __dadd_rn(ub2, block_ub[w / BM_BLOCK]);
+                            }
+                            if (pruned(ub2)) keep = false;
+                        }
+                        if (keep && qc != -1 && doc_coll[d] != qc) keep = false;
+                        if (keep) {
+                            const double dl = (double)doclen[d];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (wf[e] >= 0)
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[tr[e].lo + tr[e].cur + wf[e]], dl, avgdl, k1, b));
+                            for (int e = 8 > t ? 8 : t; e < nt; ++e) {
+                                const int64_t w = where_far(e);
+                                if (w >= 0)
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[w], dl, avgdl, k1, b));
                             }
                         }
-                        tk.push(owner, score, (int64_t)d);
                     }
+                    push(keep, score, (int64_t)d);
                 }
-            } else {   // no room for the bits (many terms): every posting takes the searching sweep
-                for (int i = threadIdx.x; i < total; i += BM_THREADS) work[i] = (uint16_t)i;
-                if (threadIdx.x == 0) n_surv = total;
-            }
-            __syncthreads();
-            const int n_work = n_surv;
-            fetch(threadIdx.x < n_work ? (int)work[threadIdx.x] : -1);
-            for (int base = 0; base < n_work; base += BM_THREADS) {
-                const int j = base + threadIdx.x;
-                const int t = n_t, off = n_off;
-                const int32_t d = n_d, tf_own = n_tf;
-                const float dl_own = n_dl;
-                fetch(j + BM_THREADS < n_work ? (int)work[j + BM_THREADS] : -1);
-                bool owner = false;
-                double score = 0.0;
-                if (j < n_work) owner = score_full(t, off, d, dl_own, tf_own, score);
-                tk.push(owner, score, (int64_t)d);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) n_surv = 0;
-        }
-        __syncthreads();
+            };
 
-        // ---- phase 2: the survivors, densely ----
-        const int ns = n_surv;
-        for (int base = 0; base < ns; base += BM_THREADS) {
-            const int j = base + threadIdx.x;
-            bool keep = j < ns;
-            double score = 0.0;
-            int32_t d = 0;
-            if (keep) {
-                int t = 0, at;
-                if (masked) {   // survivor = doc slot: owner = lowest term bit, position searched
-                    d = (int32_t)(first + surv[j]);
-                    t = __ffs((int)mask[surv[j]]) - 1;
-                    at = tr[t].lds_off + find_doc(st_doc + tr[t].lds_off, tr[t].sub, d);
-                } else {        // survivor = staged index of the owner posting
-                    at = surv[j];
-                    while (t + 1 < nt && at >= tr[t + 1].lds_off) ++t;   // lds_off ascends with t
-                    d = st_doc[at];
+            // ---- phase 1 (LDS only): owners, which terms hold the doc, bound against theta ----
+            const bool middle = !masked && have_theta && (last - first) < 32 * (int64_t)total;
+            if (masked || middle) {
+                const int w = masked ? (int)(last - first) : 1;
+                if (masked) {
+                    const int words = (w + spw - 1) >> ms;
+                    for (int i = threadIdx.x; i < words; i += BM_THREADS) mask[i] = 0u;
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < total; i += BM_THREADS) {
+                        int t = 0;
+                        while (i >= t_prefix[t + 1]) ++t;
+                        const int slot = (int)(st_doc[tr[t].lds_off + (i - t_prefix[t])] - first);
+                        atomicOr(&mask[slot >> ms], 1u << (((slot & (spw - 1)) << 3) + t));
+                    }
+                    __syncthreads();
                 }
-                // posting index of the doc in every term that holds it (first 8 terms in
-                // registers -- static indexing only --, the rest searched again when needed)
-                int64_t where[8];
-                uint32_t present = 0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    where[e] = -1;
-                    if (e >= t && e < nt) {
-                        const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-                        if (f >= 0) {
-                            where[e] = tr[e].lo + tr[e].cur + f;
-                            present |= 1u << e;
+                // masked: the candidate slots, BM_WINDOW slots (= the survivor list's capacity) at a
+                // time; else one round over the staged postings
+                for (int c0 = 0; c0 < w; c0 += BM_WINDOW) {
+                    if (masked) {
+                        const int cend = c0 + BM_WINDOW < w ? c0 + BM_WINDOW : w;
+                        for (int wd = (c0 >> ms) + (int)threadIdx.x; wd < ((cend + spw - 1) >> ms); wd += BM_THREADS) {
+                            const uint32_t v = mask[wd];
+                            if (!v) continue;
+                            for (int u = 0; u < spw; ++u) {
+                                const uint32_t m = ms ? (v >> (u << 3)) & 0xFFu : v;
+                                if (!m) continue;
+                                if (conjunctive && __popc(m) < nt) continue;
+                                if (have_theta) {
+                                    double ub = 0.0;
+                                    for (uint32_t r = m; r; r &= r - 1) ub = __dadd_rn(ub, t_ub[__ffs((int)r) - 1]);
+                                    if (pruned(ub)) continue;
+                                }
+                                surv[atomicAdd(&n_surv, 1)] = (uint16_t)((wd << ms) + u);
+                            }
+                        }
+                    } else {
+                        // moderately dense lists and a threshold to prune with: LDS-only owner / bound
+                        // search (a doc is dropped on the sum of its terms' bounds before any gather;
+                        // the sweep below would find most docs shared and score them all)
+                        for (int i = threadIdx.x; i < total; i += BM_THREADS) {
+                            int t = 0;
+                            while (i >= t_prefix[t + 1]) ++t;
+                            const int off = i - t_prefix[t];
+                            const int32_t d = st_doc[tr[t].lds_off + off];
+                            bool owner = true;
+                            for (int e = 0; e < t && owner; ++e)
+                                if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) owner = false;
+                            if (!owner) continue;
+                            int present = 1;
+                            double ub = __dadd_rn(0.0, t_ub[t]);
+                            for (int e = t + 1; e < nt; ++e)
+                                if (find_doc(st_doc + tr[e].lds_off, tr[e].sub, d) >= 0) {
+                                    ++present;
+                                    ub = __dadd_rn(ub, t_ub[e]);
+                                }
+                            if (conjunctive && present < nt) continue;
+                            if (pruned(ub)) continue;
+                            surv[atomicAdd(&n_surv, 1)] = (uint16_t)(tr[t].lds_off + off);
                         }
                     }
+                    __syncthreads();
+                    const int ns = n_surv;
+                    phase2(masked, ns);
+                    __syncthreads();
+                    if (threadIdx.x == 0) n_surv = 0;
+                    __syncthreads();
                 }
-                auto where_far = [&](int e) -> int64_t {   // e >= 8
-                    const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
-                    return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
+            } else {
+                // sparse lists (or no threshold yet): every owner is scored in the same sweep that finds it.
+                // Sparse lists share few docs, so nearly every "is this doc in list e" question is
+                // answered NO: a Bloom bit per (list, doc hash) in the idle scratch buffer answers
+                // those with one LDS read instead of a binary search (a chain of ~11); a set bit is
+                // confirmed by the search, so the result is exact.  The doc-length and own-tf gathers
+                // of the NEXT sweep step are requested before the current one is worked on.
+                // bits per list: the largest power of two (<= 32768) that fits the buffer nt times next
+                // to a work list that could take every posting of the pass (16 bits each)
+                constexpr int SCR_WORDS = BM_WINDOW + BM_WINDOW / 2;
+                int bwords = 1024;
+                while (bwords >= 128 && nt * bwords + (total + 1) / 2 > SCR_WORDS) bwords >>= 1;
+                const bool bloom = bwords >= 128;
+                const int bl2 = 31 - __clz(bwords * 32);
+                if (bloom) {
+                    for (int i = threadIdx.x; i < nt * bwords; i += BM_THREADS) scratch[i] = 0u;
+                    __syncthreads();
+                    for (int i = threadIdx.x; i < total; i += BM_THREADS) {
+                        int t = 0;
+                        while (i >= t_prefix[t + 1]) ++t;
+                        const uint32_t h = ((uint32_t)st_doc[tr[t].lds_off + (i - t_prefix[t])] * 2654435761u) >> (32 - bl2);
+                        atomicOr(&scratch[t * bwords + (h >> 5)], 1u << (h & 31));
+                    }
+                    __syncthreads();
+                }
+                auto lookup = [&](int e, int32_t d) -> int {   // index of d in list e's staged ids, or -1
+                    if (bloom) {
+                        const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
+                        if (!((scratch[e * bwords + (h >> 5)] >> (h & 31)) & 1u)) return -1;
+                    }
+                    return find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
                 };
-                if (have_theta && block_ub) {
-                    double ub2 = 0.0;
+                // the searching version of "score posting (t, off) if it owns doc d"
+                auto score_full = [&](int t, int off, int32_t d, float dl_own, int32_t tf_own, double& score) -> bool {
+                    for (int e = 0; e < t; ++e)
+                        if (lookup(e, d) >= 0) return false;
+                    int present = 0;
+                    int wf[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (where[e] >= 0) ub2 = __dadd_rn(ub2, block_ub[where[e] / BM_BLOCK]);
-                    for (int e = 8 > t ? 8 : t; e < nt; ++e) {
-                        const int64_t w = where_far(e);
-                        if (w >= 0) ub2 = __dadd_rn(ub2, block_ub[w / BM_BLOCK]);
+                    for (int e = 0; e < 8; ++e) {
+                        wf[e] = -1;
+                        if (e >= t && e < nt) {
+                            wf[e] = e == t ? off : lookup(e, d);
+                            if (wf[e] >= 0) ++present;
+                        }
                     }
-                    if (!(ub2 > theta)) keep = false;
-                }
-                if (keep && qc != -1 && doc_coll[d] != qc) keep = false;
-                if (keep) {
-                    const double dl = (double)doclen[d];
+                    auto far = [&](int e) -> int64_t {   // terms beyond the 8th: searched when needed
+                        const int f = e < t ? -1 : (e == t ? off : lookup(e, d));
+                        return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
+                    };
+                    for (int e = 8; e < nt; ++e) present += far(e) >= 0 ? 1 : 0;
+                    if (conjunctive && present < nt) return false;
+                    if (qc != -1 && doc_coll[d] != qc) return false;
+                    const double dl = (double)dl_own;
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (where[e] >= 0)
-                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[where[e]], dl, avgdl, k1, b));
-                    for (int e = 8 > t ? 8 : t; e < nt; ++e) {
-                        const int64_t w = where_far(e);
+                        if (wf[e] >= 0)
+                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)(e == t ? tf_own : post_tf[tr[e].lo + tr[e].cur + wf[e]]), dl, avgdl, k1, b));
+                    for (int e = 8; e < nt; ++e) {
+                        const int64_t w = far(e);
                         if (w >= 0)
-                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[w], dl, avgdl, k1, b));
+                            score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)(e == t ? tf_own : post_tf[w]), dl, avgdl, k1, b));
                     }
+                    return true;
+                };
+                int n_t = 0, n_off = 0;
+                int32_t n_d = 0, n_tf = 0;
+                float n_dl = 0.f;
+                auto fetch = [&](int i) {
+                    if (i >= 0 && i < total) {
+                        n_t = 0;
+                        while (i >= t_prefix[n_t + 1]) ++n_t;
+                        n_off = i - t_prefix[n_t];
+                        n_d = st_doc[tr[n_t].lds_off + n_off];
+                        n_dl = doclen[n_d];
+                        n_tf = post_tf[tr[n_t].lo + tr[n_t].cur + n_off];
+                    }
+                };
+                // With the filter, sweep 1 never searches: a posting whose doc shows in no other list's
+                // bits is the doc's only posting (owner, one contribution) and is scored at once; the
+                // few with a set bit -- which a wave would otherwise wait for, lane by lane -- go to a
+                // work list (behind the bits in the same buffer) that sweep 2 walks densely.
+                static_assert(2 * (BM_WINDOW + BM_WINDOW / 2) >= BM_STAGE, "work list of a pass without the filter");
+                uint16_t* work = reinterpret_cast<uint16_t*>(bloom ? scratch + nt * bwords : scratch);
+                // (n_surv is 0 here: it counts the work list now)
+                if (bloom) {
+                    // list by list: everything that depends on the term is uniform (scalar registers)
+                    for (int t = 0; t < nt; ++t) {
+                        const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
+                        const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
+                        const int pre = __builtin_amdgcn_readfirstlane(t_prefix[t]);
+                        const int32_t* tf_t = post_tf + tr[t].lo + tr[t].cur;
+                        const double idf_t = t_idf[t], ub_t = t_ub[t];
+                        const bool single_ok = !(conjunctive && nt > 1);
+                        for (int base = 0; base < sub; base += BM_THREADS) {
+                            const int i = base + (int)threadIdx.x;
+                            bool owner = false;
+                            double score = 0.0;
+                            int32_t d = 0;
+                            if (i < sub) {
+                                d = st_doc[off0 + i];
+                                const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
+                                const uint32_t w = h >> 5, bit = 1u << (h & 31);
+                                bool alone = true;
+                                for (int e = 0; e < nt; ++e)
+                                    if (e != t && (scratch[e * bwords + w] & bit)) alone = false;
+                                if (!alone) {
+                                    work[atomicAdd(&n_surv, 1)] = (uint16_t)(pre + i);
+                                } else if (single_ok && !(ub_t < th_s) && !(ub_t < thg) && !(qc != -1 && doc_coll[d] != qc)) {
+                                    // (ub_t < threshold: no posting of this list can enter on its own)
+                                    owner = true;
+                                    score = __dadd_rn(score, bm25_contrib(idf_t, (double)tf_t[i], (double)doclen[d], avgdl, k1, b));
+                                }
+                            }
+                            push(owner, score, (int64_t)d);
+                        }
+                    }
+                } else {   // no room for the bits (many terms): every posting takes the searching sweep
+                    for (int i = threadIdx.x; i < total; i += BM_THREADS) work[i] = (uint16_t)i;
+                    if (threadIdx.x == 0) n_surv = total;
+                }
+                __syncthreads();
+                const int n_work = n_surv;
+                fetch((int)threadIdx.x < n_work ? (int)work[threadIdx.x] : -1);
+                for (int base = 0; base < n_work; base += BM_THREADS) {
+                    const int j = base + threadIdx.x;
+                    const int t = n_t, off = n_off;
+                    const int32_t d = n_d, tf_own = n_tf;
+                    const float dl_own = n_dl;
+                    fetch(j + BM_THREADS < n_work ? (int)work[j + BM_THREADS] : -1);
+                    bool owner = false;
+                    double score = 0.0;
+                    if (j < n_work) owner = score_full(t, off, d, dl_own, tf_own, score);
+                    push(owner, score, (int64_t)d);
                 }
             }
-            tk.push(keep, score, (int64_t)d);
+            __syncthreads();
+            // a fresh theta pays for the select once enough docs have entered since the last one
+            if (b_cnt >= k && b_cnt - last_compact >= 64) {
+                tk.compact();
+                if (threadIdx.x == 0) {
+                    last_compact = b_cnt;
+                    // a lower bound of this slice's k-th best bounds the query's k-th best from below
+                    if (S > 1 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+                }
+            }
+            if (threadIdx.x == 0) {
+                for (int t = 0; t < nt; ++t) tr[t].cur += tr[t].sub;
+                remaining -= total;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        // a fresh theta pays for the sort once enough docs have entered since the last one
-        if (b_cnt >= k && b_cnt - last_compact >= 64) {
-            tk.compact();
-            if (threadIdx.x == 0) last_compact = b_cnt;
+        const int n = tk.finish();
+        if (S == 1) {
+            for (int i = threadIdx.x; i < k; i += BM_THREADS) {
+                out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
+                out_id[(int64_t)q * k + i] = i < n ? b_id[i] + id_base : -1;
+            }
+            if (threadIdx.x == 0) out_cnt[q] = n;
+        } else {
+            for (int i = threadIdx.x; i < n; i += BM_THREADS) {
+                slice_s[(int64_t)item * k + i] = b_s[i];
+                slice_id[(int64_t)item * k + i] = b_id[i] + id_base;
+            }
+            if (threadIdx.x == 0) {
+                slice_cnt[item] = n;
+                if (n >= k) atomicMax(&theta_glob[q], (unsigned long long)dkey(b_s[k - 1]));
+            }
         }
-        if (threadIdx.x == 0) {
-            for (int t = 0; t < nt; ++t) tr[t].cur += tr[t].sub;
-            remaining -= total;
+    }
+}
+
+// The best k of a sliced query's per-slice lists (order: score desc, id asc -- the slices hold
+// disjoint docs, so there are no duplicates to resolve).
+constexpr int BMM_THREADS = 256, BMM_CAP = 512;
+__global__ __launch_bounds__(BMM_THREADS) void bm25_merge_kernel(
+    const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_item0,
+    const double* __restrict__ slice_s, const int64_t* __restrict__ slice_id,
+    const int32_t* __restrict__ slice_cnt, int k, double* __restrict__ out_s,
+    int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
+    static_assert(BMM_CAP >= THR_TOPK_MAX + BMM_THREADS, "merge buffer");
+    __shared__ double b_s[BMM_CAP];
+    __shared__ int64_t b_id[BMM_CAP];
+    __shared__ int b_cnt;
+    __shared__ double th_s;
+    __shared__ int64_t th_id;
+    const int q = blockIdx.x;
+    const int S = q_S[q];
+    if (S == 1) return;   // written by the item itself
+    const int item0 = q_item0[q];
+    BlockTopK<BMM_CAP, BMM_THREADS> tk;
+    tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);
+    for (int base = 0; base < S * k; base += BMM_THREADS) {
+        const int idx = base + threadIdx.x;
+        const int sl = idx / k, j = idx - sl * k;
+        const bool ok = sl < S && j < slice_cnt[item0 + sl];
+        double sc = 0.0;
+        int64_t id = 0;
+        if (ok) {
+            sc = slice_s[(int64_t)(item0 + sl) * k + j];
+            id = slice_id[(int64_t)(item0 + sl) * k + j];
         }
-        __syncthreads();
+        tk.push(ok, sc, id);
     }
     const int n = tk.finish();
-    for (int i = threadIdx.x; i < k; i += BM_THREADS) {
+    for (int i = threadIdx.x; i < k; i += BMM_THREADS) {
         out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
-        out_id[(int64_t)q * k + i] = i < n ? b_id[i] + id_base : -1;
+        out_id[(int64_t)q * k + i] = i < n ? b_id[i] : -1;
     }
     if (threadIdx.x == 0) out_cnt[q] = n;
+}
+
+// ---- workspace of thr_bm25_topk ----
+struct BmLayout {
+    size_t off_ctl, off_theta, off_tot, off_nt, off_S, off_item0, off_long, off_qterms, off_items,
+        off_ipos, off_ss, off_sid, off_scnt, total;
+    int cap;
+};
+static BmLayout bm_layout(int nq, int mt, int k) {
+    BmLayout L;
+    L.cap = nq + BM_EXTRA_ITEMS;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    L.off_ctl = take(sizeof(int32_t) * 4);                 // [0] items, [1] next item   } zeroed
+    L.off_theta = take(sizeof(unsigned long long) * nq);   // shared thresholds (keys)   } per call
+    L.off_tot = take(sizeof(int64_t) * nq);
+    L.off_nt = take(sizeof(int32_t) * nq);
+    L.off_S = take(sizeof(int32_t) * nq);
+    L.off_item0 = take(sizeof(int32_t) * nq);
+    L.off_long = take(sizeof(int32_t) * nq);
+    L.off_qterms = take(sizeof(int32_t) * (size_t)nq * mt);
+    L.off_items = take(sizeof(int2) * (size_t)L.cap);
+    L.off_ipos = take(sizeof(int32_t) * (size_t)(L.cap + 1) * mt);
+    L.off_ss = take(sizeof(double) * (size_t)L.cap * k);
+    L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
+    L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
+    L.total = off;
+    return L;
+}
+
+static int bm_num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 }  // namespace thr
@@ -551,6 +841,11 @@ extern "C" int thr_bm25_bounds(const int64_t* rowptr, const int32_t* post_doc, c
     return launch_status();
 }
 
+extern "C" size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k) {
+    if (n_queries <= 0 || max_terms <= 0 || k <= 0) return 0;
+    return bm_layout(n_queries, max_terms, k).total;
+}
+
 extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
                              const float* doclen, const double* idf, const double* term_ub,
                              const double* block_ub, double avgdl, double k1, double b,
@@ -558,34 +853,66 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                              const int32_t* query_terms, int n_queries, int max_terms, int k,
                              int conjunctive, const int32_t* doc_coll, const int32_t* query_coll,
                              double* out_scores, int64_t* out_ids, int32_t* out_counts,
-                             thr_stream_t stream) {
+                             void* workspace, size_t workspace_bytes, thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !doclen || !idf || !query_terms ||
-                      !out_scores || !out_ids || !out_counts,
+                      !out_scores || !out_ids || !out_counts || !workspace,
                   THR_ERR_INVALID);
     THR_RETURN_IF(n_docs <= 0 || n_vocab <= 0 || n_queries <= 0 || k <= 0 || k > THR_TOPK_MAX ||
                       max_terms <= 0 || max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
                   THR_ERR_INVALID);
     THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
-    // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two queries per CU --
+    const BmLayout L = bm_layout(n_queries, max_terms, k);
+    THR_RETURN_IF(workspace_bytes < L.total, THR_ERR_WORKSPACE);
+    char* ws = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* ctl = (int32_t*)(ws + L.off_ctl);
+    unsigned long long* theta = (unsigned long long*)(ws + L.off_theta);
+    int64_t* q_tot = (int64_t*)(ws + L.off_tot);
+    int32_t* q_nt = (int32_t*)(ws + L.off_nt);
+    int32_t* q_S = (int32_t*)(ws + L.off_S);
+    int32_t* q_item0 = (int32_t*)(ws + L.off_item0);
+    int32_t* q_long = (int32_t*)(ws + L.off_long);
+    int32_t* q_terms = (int32_t*)(ws + L.off_qterms);
+    int2* items = (int2*)(ws + L.off_items);
+    int32_t* ipos = (int32_t*)(ws + L.off_ipos);
+    double* slice_s = (double*)(ws + L.off_ss);
+    int64_t* slice_id = (int64_t*)(ws + L.off_sid);
+    int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
+    hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
+                       n_queries, max_terms, L.cap, ctl, q_tot, q_nt, q_S, q_item0, q_long, q_terms, items);
+    const int64_t edge_threads = (int64_t)L.cap * max_terms;
+    hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
+                       rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, ipos);
+    int rc = launch_status();
+    if (rc) return rc;
+    // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two workgroups per CU --
     // a four-term query of the bench (6.7 K postings) is one pass.  THR_BM25_SHAPE=small selects
-    // 256 threads / 4096 ids / 39 KiB, four queries per CU: the fixed cost of a query (set-up,
-    // staging, the final sort) overlaps four ways, which wins when every list is short (2048
-    // queries over lists of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise
-    // (bench mix 0.46 ms against 0.42 ms; 256 stop-word queries 23 ms against 12 ms).
+    // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
+    // final sort) overlaps four ways, which wins when every list is short (2048 queries over lists
+    // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
     static int small = -1;
     if (small < 0) {
-        const char* e = getenv("THR_BM25_SHAPE");
-        small = (e && e[0] == 's') ? 1 : 0;
+        const char* ev = getenv("THR_BM25_SHAPE");
+        small = (ev && ev[0] == 's') ? 1 : 0;
     }
     const bool big = !small;
+    // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
+    int grid = bm_num_cus() * (big ? 2 : 4);
+    if (grid > L.cap) grid = L.cap;
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
-    hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(n_queries), dim3(T), 0, (hipStream_t)stream, \
-                       rowptr, post_doc, post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr, \
-                       avgdl, k1, b, n_docs, n_vocab, id_base, query_terms, max_terms, k, conjunctive, \
-                       doc_coll, query_coll, out_scores, out_ids, out_counts)
+    hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
+                       post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr, avgdl, k1, b,   \
+                       id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
+                       q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,       \
+                       out_ids, out_counts)
     if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024);
     else THR_BM25_LAUNCH(256, 4096, 2048, 512);
 #undef THR_BM25_LAUNCH
+    if ((rc = launch_status())) return rc;
+    hipLaunchKernelGGL(bm25_merge_kernel, dim3(n_queries), dim3(BMM_THREADS), 0, st, q_S, q_item0,
+                       slice_s, slice_id, slice_cnt, k, out_scores, out_ids, out_counts);
     return launch_status();
 }

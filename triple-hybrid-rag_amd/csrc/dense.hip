@@ -1396,6 +1396,14 @@ static int qreg_shape(int dim) {
     return v;
 }
 constexpr int QREG_MAX_SEG = 1024;
+// The register-resident scans address a lane's candidate segment with a 32-bit byte offset from
+// the start of the candidate area ((q * CAND_CAP + segment start) * sizeof(Cand)): a batch may
+// hold as many (padded) queries as keep every offset below 2^32.
+static int qreg_max_queries(int dim) {
+    const int qt = 32 * qreg_waves(dim);
+    const int64_t m = (int64_t)UINT32_MAX / ((int64_t)CAND_CAP * (int64_t)sizeof(Cand));
+    return (int)(m / qt * qt);
+}
 
 static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind = KIND_F32,
                            int dim = 0, bool packed = false) {
@@ -1878,6 +1886,11 @@ extern "C" size_t thr_dense_f16_workspace_bytes(int64_t n_docs, int dim, int n_q
     return a > b ? a : b;
 }
 
+extern "C" int thr_dense_f16_max_queries(int dim, int packed) {
+    if (dim != 512 && dim != 768 && dim != 1024) return 0;
+    return packed ? qreg_max_queries(dim) : INT32_MAX;
+}
+
 extern "C" int thr_dense_f16_query_tile(int dim, int packed, int n_queries) {
     if (dim != 512 && dim != 768 && dim != 1024) return 0;
     (void)n_queries;
@@ -1927,6 +1940,8 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
     THR_RETURN_IF(!(doc_rel_err >= 0.0) || !(doc_rel_err < 1.0), THR_ERR_INVALID);
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
+    // (32-bit candidate-segment offsets: thr_dense_f16_max_queries; the caller splits the batch)
+    THR_RETURN_IF(docs16 != nullptr && n_queries > qreg_max_queries(dim), THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, docs16 != nullptr);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
@@ -1967,6 +1982,7 @@ extern "C" int thr_dense_scan_probe_f16(const float* docs, const uint16_t* docs1
     THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
     THR_RETURN_IF(n_docs <= 0 || n_docs >= (int64_t)1 << ROW_BITS_F16 || n_queries <= 0,
                   THR_ERR_INVALID);
+    THR_RETURN_IF(docs16 != nullptr && n_queries > qreg_max_queries(dim), THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim, docs16 != nullptr);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
@@ -1997,6 +2013,7 @@ extern "C" int thr_dense_scan_stamps_f16(const uint16_t* docs16, int64_t n_docs,
     THR_RETURN_IF(n_docs <= 0 || n_queries <= 0, THR_ERR_INVALID);
     // (only the 4-wave-block kernel has a stamped build: THR_DENSE_F16=q, or dim 1024)
     THR_RETURN_IF(qreg_staggered(dim), THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_queries > qreg_max_queries(dim), THR_ERR_UNSUPPORTED);
     const DensePlan p = make_plan(n_docs, n_queries, 128, KIND_F16, dim, true);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;

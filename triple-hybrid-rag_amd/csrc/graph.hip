@@ -259,14 +259,20 @@ __global__ __launch_bounds__(GR_THREADS) void graph_topk_kernel(
 // array (1 byte per entity, 0xFF = not reached) and
 //   1. BFS, level-synchronous, by SCANNING the distance array for the entities of the previous
 //      level (no frontier lists); a wave expands one frontier entity at a time, lanes over its
-//      edges.  The distance bytes are read with L1-bypassing loads (the array is rewritten level
-//      after level by the same CU) and only ever change 0xFF -> level, so racing writers agree;
+//      edges.  The distance bytes are written and read with agent-scope relaxed atomics (the
+//      array is rewritten level after level by the same CU), fenced at every level barrier, and
+//      only ever change 0xFF -> level, so racing writers agree;
 //   2. scores every chunk of the shard from the TRANSPOSED mention CSR (chunk -> (entity, conf),
 //      in (entity asc, mention) order -- built once at index set-up): one thread per chunk sums
 //      conf/(1+dist) left to right in float64, which is the oracle's order, then the streaming
 //      block top-k.  O(E + mentions) per query instead of O(reached): a rare, slow, exact path.
 // ---------------------------------------------------------------------------------------------
-constexpr int GR_FB_BLOCKS = 16;
+// (64 workgroups: a quarter of the CUs -- a batch of many hub-seeded queries costs
+// O(E * hops + mentions) per query and would serialise on fewer; 1 byte per entity and workgroup)
+constexpr int GR_FB_BLOCKS = 64;
+__device__ __forceinline__ void gr_set_dist(uint8_t* dist, int64_t e, uint8_t v) {
+    __hip_atomic_store(dist + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ uint32_t gr_dist(const uint8_t* dist, uint32_t e) {
     const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(dist) + (e >> 2),
@@ -292,12 +298,17 @@ __global__ __launch_bounds__(GR_THREADS) void graph_fallback_kernel(
         if (!(out_flags[q] & THR_FLAG_OVERFLOW)) continue;   // same answer in every thread
         __syncthreads();
         for (int64_t i = threadIdx.x; i < e_pad / 4; i += GR_THREADS)
-            reinterpret_cast<uint32_t*>(dist)[i] = 0xffffffffu;
+            __hip_atomic_store(reinterpret_cast<uint32_t*>(dist) + i, 0xffffffffu, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        // (the distance bytes are written and read with agent-scope relaxed atomics; a release /
+        // acquire fence pair around each barrier orders the levels)
+        __threadfence();
         __syncthreads();
         if (threadIdx.x < max_seeds) {
             const int32_t e = query_seeds[(int64_t)q * max_seeds + threadIdx.x];
-            if (e >= 0 && e < n_entities) dist[e] = 0;
+            if (e >= 0 && e < n_entities) gr_set_dist(dist, e, 0);
         }
+        __threadfence();
         __syncthreads();
         for (int lvl = 1; lvl <= hops; ++lvl) {
             for (int64_t base = 0; base < n_entities; base += GR_THREADS) {
@@ -312,10 +323,11 @@ __global__ __launch_bounds__(GR_THREADS) void graph_fallback_kernel(
                     for (int64_t j = lo + lane; j < hi; j += WAVE) {
                         const int32_t t = ent_col[j];
                         if (t >= 0 && t < n_entities && gr_dist(dist, (uint32_t)t) == 0xffu)
-                            dist[t] = (uint8_t)lvl;
+                            gr_set_dist(dist, t, (uint8_t)lvl);
                     }
                 }
             }
+            __threadfence();
             __syncthreads();
         }
         BlockTopK<GrFull::CAP, GR_THREADS> tk;

@@ -151,13 +151,17 @@ struct BlockTopK {
             }
         }
         __syncthreads();
-        if (*count + (int)blockDim.x > CAP) compact();
+        // every thread takes the same decision: the count is read between two barriers, so no
+        // wave can be back in push() (and add to it) while another still reads it
+        const int c = *count;
+        __syncthreads();
+        if (c + (int)blockDim.x > CAP) compact();
     }
     __device__ void compact() {
         __shared__ int hist[256];
         __shared__ int sel[2];      // bin of the k-th, entries in the bins above it
         __shared__ int kept;
-        const int c = *count;       // (uniform: read after a barrier by every caller)
+        const int c = *count;       // (uniform: nobody adds to it between a barrier and this call)
         if (c < k) return;
         const int lane = threadIdx.x & (WAVE - 1);
         uint32_t prefix = 0;

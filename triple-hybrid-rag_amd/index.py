@@ -61,6 +61,7 @@ class GpuIndex:
         self.tokens_packed = False
         self._ws: Optional[torch.Tensor] = None
         self._ws_rescue: Optional[torch.Tensor] = None
+        self._ws_lex: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------ builders
     def _t(self, a, dtype):
@@ -183,6 +184,12 @@ class GpuIndex:
             self._ws_rescue = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self
 
+    def max_batch(self) -> int:
+        """Queries one dense_search call hands to the scan at once (larger batches are split)."""
+        if self.shortlist == "f16":
+            return N.dense_f16_max_queries(self.dim, True)
+        return 1 << 30
+
     def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
                      rescue: bool = True, sync: bool = True, collections=None):
         """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
@@ -192,7 +199,23 @@ class GpuIndex:
         collections: int32 [nq] collection id per query (-1 = unfiltered), applied before the
         ranking (set_collections)."""
         queries = self._t(queries, torch.float32)
-        dc, qc = self._qcoll(collections, queries.shape[0])
+        nq = queries.shape[0]
+        if self.shortlist == "f16":
+            # one call of the copy scan takes at most dense_f16_max_queries queries (its
+            # candidate-segment offsets are 32 bits): larger batches go through in pieces
+            step = self.max_batch()
+            if nq > step:
+                S, I, cnt, _ = N._alloc_out(nq, k, self.device)
+                n_rescued = 0 if sync else torch.zeros(1, dtype=torch.int32, device=self.device)
+                coll = None if collections is None else self._t(collections, torch.int32)
+                for lo in range(0, nq, step):
+                    hi = min(nq, lo + step)
+                    s_, i_, c_, r_ = self.dense_search(queries[lo:hi], k, kprime, rescue, sync,
+                                                       None if coll is None else coll[lo:hi])
+                    S[lo:hi], I[lo:hi], cnt[lo:hi] = s_, i_, c_
+                    n_rescued = n_rescued + r_
+                return S, I, cnt, n_rescued
+        dc, qc = self._qcoll(collections, nq)
         if self.shortlist != "f32":
             # tau must sit clearly below the k-th score for the quantisation-aware certificate:
             # k' = 192 puts it ~6e-3 below on a 1M-row corpus, ~6x the f16 error bound
@@ -245,10 +268,13 @@ class GpuIndex:
         L = self.lex
         qt = self._t(query_terms, torch.int32)
         dc, qc = self._qcoll(collections, qt.shape[0])
+        need = N.bm25_workspace_bytes(qt.shape[0], qt.shape[1], k)
+        if self._ws_lex is None or self._ws_lex.numel() < need:   # kept: no allocation per search
+            self._ws_lex = torch.empty(need, dtype=torch.uint8, device=self.device)
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
                            L["avgdl"], qt, k, self.doc_base, L["k1"], L["b"],
                            bounds=L["bounds"] if prune else None, conjunctive=conjunctive,
-                           doc_coll=dc, query_coll=qc)
+                           doc_coll=dc, query_coll=qc, workspace=self._ws_lex)
 
     def graph_search(self, query_seeds: torch.Tensor, k: int, hops: int = 2):
         G = self.graph

@@ -87,6 +87,25 @@ def _zipf_cdf(v: int) -> np.ndarray:
     return c / c[-1]
 
 
+def _lexical_block(b: int, v: int, cdf: np.ndarray):
+    """Block b of the global corpus: (term [BLOCK, draws] sorted per row, tf, keep mask)."""
+    draws = TERMS_PER_DOC + 8
+    r = _rng(SEED_DOCS, 1, b)
+    t = np.searchsorted(cdf, r.random((BLOCK, draws))).astype(np.int32)
+    t = np.minimum(t, v - 1)
+    tf = r.geometric(0.5, size=(BLOCK, draws)).astype(np.int32)  # = 1 + Geometric0(0.5)
+    t.sort(axis=1)
+    keep = np.ones_like(t, dtype=bool)
+    keep[:, 1:] = t[:, 1:] != t[:, :-1]
+    # at most 32 distinct terms per doc
+    keep &= np.cumsum(keep, axis=1) <= TERMS_PER_DOC
+    return t, tf, keep
+
+
+def _workers(n_tasks: int) -> int:
+    return max(1, min(16, os.cpu_count() or 1, n_tasks))
+
+
 def lexical_rows(start: int, count: int, n_docs_global: int
                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Per-doc bags for rows [start, start+count): (doc_local i32[nnz], term i32[nnz],
@@ -94,27 +113,44 @@ def lexical_rows(start: int, count: int, n_docs_global: int
     tf ~ 1 + Geometric(0.5)."""
     v = vocab_size(n_docs_global)
     cdf = _zipf_cdf(v)
-    docs, terms, tfs = [], [], []
     b0, b1 = start // BLOCK, (start + count - 1) // BLOCK
     draws = TERMS_PER_DOC + 8
-    for b in range(b0, b1 + 1):
-        r = _rng(SEED_DOCS, 1, b)
-        t = np.searchsorted(cdf, r.random((BLOCK, draws))).astype(np.int32)
-        t = np.minimum(t, v - 1)
-        tf = r.geometric(0.5, size=(BLOCK, draws)).astype(np.int32)  # = 1 + Geometric0(0.5)
-        t.sort(axis=1)
-        keep = np.ones_like(t, dtype=bool)
-        keep[:, 1:] = t[:, 1:] != t[:, :-1]
-        # at most 32 distinct terms per doc
-        keep &= np.cumsum(keep, axis=1) <= TERMS_PER_DOC
+
+    def block(b):
+        t, tf, keep = _lexical_block(b, v, cdf)
         lo = max(start, b * BLOCK) - b * BLOCK
         hi = min(start + count, (b + 1) * BLOCK) - b * BLOCK
-        rows = np.repeat(np.arange(BLOCK, dtype=np.int64)[:, None], draws, axis=1)
+        rows = np.repeat(np.arange(lo, hi, dtype=np.int64)[:, None], draws, axis=1)
         sel = keep[lo:hi]
-        docs.append((rows[lo:hi][sel] + b * BLOCK - start).astype(np.int32))
-        terms.append(t[lo:hi][sel])
-        tfs.append(tf[lo:hi][sel])
-    return np.concatenate(docs), np.concatenate(terms), np.concatenate(tfs)
+        return ((rows[sel] + b * BLOCK - start).astype(np.int32), t[lo:hi][sel], tf[lo:hi][sel])
+
+    # (numpy releases the GIL in the generators, searchsorted and sort: blocks run in parallel)
+    with ThreadPoolExecutor(max_workers=_workers(b1 - b0 + 1)) as ex:
+        parts = list(ex.map(block, range(b0, b1 + 1)))
+    return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+            np.concatenate([p[2] for p in parts]))
+
+
+def lexical_global_stats(n_docs_global: int) -> Tuple[np.ndarray, float]:
+    """(df int64 [V], sum of doc lengths) of the WHOLE corpus without keeping its rows: what a
+    shard needs for the global idf / avgdl when no other rank is there to all-reduce with."""
+    v = vocab_size(n_docs_global)
+    cdf = _zipf_cdf(v)
+    nb = (n_docs_global + BLOCK - 1) // BLOCK
+
+    def block(b):
+        t, tf, keep = _lexical_block(b, v, cdf)
+        hi = min(n_docs_global, (b + 1) * BLOCK) - b * BLOCK
+        sel = keep[:hi]
+        return t[:hi][sel], int(tf[:hi][sel].sum(dtype=np.int64))
+
+    df = np.zeros(v, dtype=np.int64)
+    sum_dl = 0
+    with ThreadPoolExecutor(max_workers=_workers(nb)) as ex:
+        for terms, s in ex.map(block, range(nb)):
+            df += np.bincount(terms, minlength=v)
+            sum_dl += s
+    return df, float(sum_dl)
 
 
 @dataclass
@@ -219,3 +255,19 @@ def query_tokens(n_queries: int, q_tokens: int = 32, tok_dim: int = 128) -> np.n
     x = _rng(SEED_QUERIES, 3).standard_normal((n_queries, q_tokens, tok_dim)).astype(np.float32)
     x /= np.linalg.norm(x, axis=2, keepdims=True)
     return x.astype(np.float16)
+
+
+def device_tokens(start, count, d_tokens=128, tok_dim=128, seed=1234 + 3, block=8192):
+    """Unit-norm float16 token matrices [count, d_tokens, tok_dim] for global docs
+    [start, start+count), generated ON THE DEVICE in blocks seeded by the global block index
+    (a shard holds what the unsharded store holds; 32.8 GB per 1M docs never touches the host)."""
+    import torch
+    out = torch.empty((count, d_tokens, tok_dim), dtype=torch.float16, device="cuda")
+    g = torch.Generator(device="cuda")
+    for b in range(start // block, (start + count - 1) // block + 1):
+        g.manual_seed(seed * 1_000_003 + b)
+        x = torch.randn((block, d_tokens, tok_dim), generator=g, device="cuda", dtype=torch.float32)
+        x = torch.nn.functional.normalize(x, dim=2).to(torch.float16)
+        lo, hi = max(start, b * block), min(start + count, (b + 1) * block)
+        out[lo - start:hi - start] = x[lo - b * block:hi - b * block]
+    return out
