@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The BM25 kernel alone at the bench shape, for rocprofv3 --pmc passes:
-python3 scripts/pmc_bm25.py [terms] [k]"""
+python3 scripts/pmc_bm25.py [terms] [k] [bench|df256|dffull]   (query mix: the bench's, without
+stop words; 256 / 2048 queries sampled in proportion to df)"""
 import os
 import sys
 
@@ -26,7 +27,13 @@ def main():
     idx.set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, csr.sum_dl_local / n)
     dfq = csr.df_local.copy()
     dfq[dfq > 0.01 * n] = 0
-    qt = torch.from_numpy(np.ascontiguousarray(synth.lexical_queries(nq, dfq, nt))).cuda()
+    mix = sys.argv[3] if len(sys.argv) > 3 else "bench"
+    if mix == "df256":
+        qt = torch.from_numpy(np.ascontiguousarray(synth.lexical_queries(256, csr.df_local, nt))).cuda()
+    elif mix == "dffull":
+        qt = torch.from_numpy(np.ascontiguousarray(synth.lexical_queries(nq, csr.df_local, nt))).cuda()
+    else:
+        qt = torch.from_numpy(np.ascontiguousarray(synth.lexical_queries(nq, dfq, nt))).cuda()
     for _ in range(4):
         idx.bm25_search(qt, k)
     torch.cuda.synchronize()

@@ -15,7 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
-LIB_PATH = os.path.join(PKG_DIR, "libthr_hip.so")
+# THR_LIB_PATH: load another build of the library (A/B experiments of scripts/); never set in tests
+LIB_PATH = os.environ.get("THR_LIB_PATH") or os.path.join(PKG_DIR, "libthr_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                # every float64 operation on the parity paths is one IEEE rounding, as in
                # the oracle; the fp32 scan asks for FMAs explicitly
@@ -48,6 +49,25 @@ def _obj_stale(src: str) -> bool:
     return any(os.path.getmtime(d) > t for d in [src] + _headers())
 
 
+def build_variant(name: str, defines, only=("bm25",)) -> str:
+    """An A/B build: the sources in ``only`` recompiled with extra -D flags, linked with the
+    regular objects into build/libthr_<name>.so (load it with THR_LIB_PATH)."""
+    build_native()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objs = []
+    for src in sources():
+        base = os.path.basename(src)[:-4]
+        if base in only:
+            o = os.path.join(OBJ_DIR, f"{base}.{name}.o")
+            subprocess.check_call([hipcc] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-c", src, "-o", o])
+            objs.append(o)
+        else:
+            objs.append(_obj(src))
+    out = os.path.join(OBJ_DIR, f"libthr_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
 def stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -58,7 +78,7 @@ def stale() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into one shared library.  hipcc cross-compiles
     without a GPU, so this also runs in the build container."""
-    if not force and not stale():
+    if os.environ.get("THR_LIB_PATH") or (not force and not stale()):
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

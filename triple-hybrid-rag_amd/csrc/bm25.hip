@@ -333,7 +333,8 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 th_glob = g ? dkey_inv(g) : -INFINITY;
                 // no threshold anywhere yet and a long way to go: a short first pass gets one cheaply
                 // (without a threshold every staged doc is scored in full)
-                const bool warm = g != 0ull || (b_cnt >= k && th_s > -INFINITY) || remaining <= BM_STAGE;
+                // (sliced items only: an unsliced query is at most three passes long)
+                const bool warm = g != 0ull || (b_cnt >= k && th_s > -INFINITY) || remaining <= BM_STAGE || S == 1;
                 const int stage = warm ? BM_STAGE : BM_STAGE / 4;
                 int off = 0;
                 const int spare = stage - 32 * nt;   // every list gets at least 32 slots
@@ -900,7 +901,12 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     }
     const bool big = !small;
     // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
-    int grid = bm_num_cus() * (big ? 2 : 4);
+    static int per_cu = -1;
+    if (per_cu < 0) {
+        const char* ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
+        per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
+    }
+    int grid = bm_num_cus() * (per_cu ? per_cu : (big ? 2 : 4));
     if (grid > L.cap) grid = L.cap;
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \

@@ -154,7 +154,9 @@ struct BlockTopK {
         // every thread takes the same decision: the count is read between two barriers, so no
         // wave can be back in push() (and add to it) while another still reads it
         const int c = *count;
+#ifndef THR_PUSH_SINGLE_BARRIER
         __syncthreads();
+#endif
         if (c + (int)blockDim.x > CAP) compact();
     }
     __device__ void compact() {
