@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--probe-reps", type=int, default=5)
     ap.add_argument("--no-extras", "--no-f16-extra", dest="no_extras", action="store_true",
                     help="skip the other shortlist flavours, the other configs and the latency section")
+    ap.add_argument("--lexical-mix", choices=("survey", "no-stopwords"), default="survey",
+                    help="query terms of the lexical channel: survey = 4 term ids sampled in proportion to "
+                         "df (SURVEY 8d: stop words included, ~0.5M postings per query at 1M docs); "
+                         "no-stopwords = the same draw without the terms held by more than 1 %% of the docs")
     ap.add_argument("--shortlist", choices=("auto", "f16-inline", "f16", "f32"), default="auto",
                     help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16 copy; "
                          "results are the same float64-exact bits in every flavour (DESIGN.md 4.1)")
@@ -155,8 +159,10 @@ def main():
         idf = np.log(1.0 + (args.docs - df.astype(np.float64) + 0.5) / (df.astype(np.float64) + 0.5))
         index.set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, float(sdl.item()) / args.docs)
         dfq = df.copy()
-        dfq[dfq > 0.01 * args.docs] = 0          # stop words are not query terms (1 % of the docs)
-        qt = synth.lexical_queries(nq * n_replicas, dfq, 4)[replica::n_replicas]
+        dfq[dfq > 0.01 * args.docs] = 0          # the "no-stopwords" mix: no term held by > 1 % of the docs
+        qt_alt = {"survey": synth.lexical_queries(nq * n_replicas, df, 4)[replica::n_replicas],
+                  "no-stopwords": synth.lexical_queries(nq * n_replicas, dfq, 4)[replica::n_replicas]}
+        qt = qt_alt[args.lexical_mix]
     if need_graph:
         graph = synth.build_graph(args.docs, lo, hi)
         index.set_graph(graph.ent_rowptr, graph.ent_col, graph.men_rowptr, graph.men_chunk, graph.men_conf)
@@ -171,7 +177,18 @@ def main():
     gen_s = time.time() - t0
     index.reserve(nq, 100)   # workspaces are part of the resident index, not of a step
     sharded = ShardedIndex(index, group=group)
-    qd = torch.from_numpy(queries).cuda()
+    # The step starts where the reference's embed_query() starts its post-processing
+    # (rag2/embedder.py:226-241): the embedding model's 4096-d vectors, resident in HBM.  Their
+    # first ``dim`` components are the synthetic query directions at an arbitrary scale, the rest
+    # is noise that the Matryoshka truncation drops; thr_embed_postproc (truncate + float32
+    # L2-normalise) is the first kernel of every timed step.
+    raw = np.empty((nq, 4096), dtype=np.float32)
+    raw[:, :args.dim] = queries * np.float32(3.7)
+    raw[:, args.dim:] = np.random.Generator(np.random.PCG64([4321, 9, replica])).standard_normal(
+        (nq, 4096 - args.dim), dtype=np.float32)
+    raw_pinned = torch.from_numpy(raw).pin_memory()
+    raw_dev = raw_pinned.cuda()
+    qd = T._native.embed_postproc(raw_dev, args.dim)   # (the query vectors the extras below use)
     qtd = torch.from_numpy(np.ascontiguousarray(qt)).cuda() if qt is not None else None
     sd = torch.from_numpy(np.ascontiguousarray(seeds)).cuda() if seeds is not None else None
     torch.cuda.synchronize()
@@ -185,7 +202,8 @@ def main():
         if cfg == "triple_rerank":
             kw.update(qtok=qtok, rerank_top_k=100)
         w = {"lexical": 0.7, "semantic": 0.8} if cfg == "dense_bm25" else None   # configs[2]: RRF(0.8/0.7)
-        return lambda: sharded.retrieve_batch(qd, top_k=args.top_k, weights=w, **kw)
+        return lambda: sharded.retrieve_batch(T._native.embed_postproc(raw_dev, args.dim), top_k=args.top_k,
+                                              weights=w, **kw)
 
     def barrier():
         if world > 1:
@@ -258,10 +276,14 @@ def main():
                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                "frac": round(ach / peak, 4), "traffic": None,
                "launch_ms": round(ms, 4), "flops_per_launch": flops}
+        # what one launch has to read: the float16 copy (or the float32 rows), once
+        out["traffic_algorithmic"] = n_local * args.dim * (2 if name == "f16" else 4)
         pm = committed_pmc() if (name == "f16" and queries_dev is None) else None
         if pm:
             out["traffic"] = pm["hbm_read_bytes_per_launch"]
-            out["traffic_source"] = "profiles/r2_scan_f16qs_counters.json (separate rocprofv3 --pmc run, same shape)"
+            out["traffic_source"] = (os.path.relpath(PMC_PROFILE, ROOT) + " (separate rocprofv3 --pmc run, same "
+                                     "kernel and shape; not re-measured in this run)")
+            out["traffic_over_algorithmic"] = round(pm["hbm_read_bytes_per_launch"] / out["traffic_algorithmic"], 3)
             out["hbm_gbps_at_this_launch_time"] = round(pm["hbm_read_bytes_per_launch"] / (ms * 1e-3) / 1e9, 1)
             out["mfma_pipe_busy_under_pmc"] = pm.get("mfma_pipe_busy")
             out["clock_ghz_under_pmc"] = pm.get("clock_ghz")
@@ -273,6 +295,27 @@ def main():
     qps = args.steps * nq * n_replicas / elapsed   # every replica serves its own batch
     roofline = probe_scan(primary)
     head_ids = res.ids.clone()
+    per_rank = None
+    if world > 1:
+        # where this rank's share of a step goes: the scan alone, the exchange alone (the same
+        # all-gather on this step's own lists), and everything else of the step
+        from triple_hybrid_rag_amd.distributed import gather_topk_many
+        Ss_, Is_, _, _ = index.dense_search(qd, 100, sync=False)
+        pairs = [(Ss_, Is_)]
+        if head_cfg != "dense":
+            Sl_, Il_, _ = index.bm25_search(qtd, 50)
+            pairs.append((Sl_, Il_))
+        if head_cfg.startswith("triple"):
+            Sg_, Ig_, _ = index.graph_search(sd, 50, 2)
+            pairs.append((Sg_, Ig_))
+        ex_ms = event_ms(lambda: gather_topk_many(pairs, group), 5, torch)
+        step_ms = 1e3 * elapsed / args.steps
+        per_rank = {"step_ms": round(step_ms, 3), "scan_ms": roofline["launch_ms"],
+                    "exchange_ms": round(ex_ms, 3),
+                    "fixed_ms": round(step_ms - roofline["launch_ms"] - ex_ms, 3),
+                    "exchange_bytes_per_rank": int(sum(2 * 8 * s_.numel() for s_, _ in pairs)),
+                    "note": "rank 0; fixed = embed post-processing, threshold sample + select, shortlist, "
+                            "float64 rescoring, merge, fusion"}
 
     # ---- the other configs (N = 1 default run): same corpus, same batch ----
     cfg_out = {}
@@ -280,7 +323,8 @@ def main():
     if which == "all":
         for cfg in CONFIGS[1:]:
             r2, resc2, el2 = measure(step_fn(cfg))
-            cfg_out[cfg] = {"baseline_config": BASELINE_CONFIG[cfg],
+            cfg_out[cfg] = {"baseline_config": BASELINE_CONFIG[cfg] + " pipeline", "docs": args.docs,
+                            "gpus": 1, "lexical_mix": args.lexical_mix,
                             "value": round(args.steps * nq / el2, 1), "unit": "queries/s",
                             "ms_per_step": round(1e3 * el2 / args.steps, 3), "rescued_queries": resc2,
                             "_ids": r2.ids}
@@ -289,8 +333,18 @@ def main():
         Sl, Il, _ = index.bm25_search(qtd, 50)
         Sg, Ig, _ = index.graph_search(sd, 50, 2)
         fused = T._native.rrf_fuse(Il, Is, Ig, 100, 0.7, 0.8, 1.0)
-        post = int(sum(int(csr.df_local[t]) for row in qt for t in row if t >= 0))
-        ms_b = event_ms(lambda: index.bm25_search(qtd, 50), 5, torch)
+        bm = {}
+        for mix, q_ in qt_alt.items():     # the lexical kernel alone on BOTH query mixes
+            qd_ = torch.from_numpy(np.ascontiguousarray(q_)).cuda()
+            post = int(sum(int(csr.df_local[t]) for row in q_ for t in row if t >= 0))
+            ms_b = event_ms(lambda: index.bm25_search(qd_, 50), 5, torch)
+            by_b = post * 12 + nq * 64        # ids + term frequencies + doc lengths of every posting
+            bm[mix] = {"ms": round(ms_b, 3), "queries": nq, "postings_per_query": round(post / nq, 1),
+                       "algorithmic_GBps": round(by_b / ms_b / 1e6, 1),
+                       "frac_of_hbm_8TBps": round(by_b / ms_b / 1e6 / HBM_PEAK_GBPS, 4)}
+        bm["mix_of_the_timed_configs"] = args.lexical_mix
+        bm["mixes"] = {"survey": "4 term ids sampled in proportion to df (SURVEY 8d; stop words included)",
+                       "no-stopwords": "the same draw without the terms held by more than 1 % of the docs"}
         ms_g = event_ms(lambda: index.graph_search(sd, 50, 2), 5, torch)
         ms_r = event_ms(lambda: T._native.rrf_fuse(Il, Is, Ig, 10, 0.7, 0.8, 1.0), 5, torch)
         ms_m = event_ms(lambda: index.maxsim(qtok, fused[0]), 5, torch)
@@ -299,16 +353,15 @@ def main():
         # north star's "per-query embedding encode" as far as this path owns it: the model's
         # 4096-d vectors -> truncate to dim -> L2-normalise (thr_embed_postproc), and the PCIe
         # transfer of the raw batch from pinned host memory
-        raw = torch.randn((nq, 4096), dtype=torch.float32).pin_memory()
-        raw_dev = raw.cuda()
         ms_e = event_ms(lambda: T._native.embed_postproc(raw_dev, args.dim), 5, torch)
-        ms_h = event_ms(lambda: raw.cuda(non_blocking=True), 5, torch)
+        ms_h = event_ms(lambda: raw_pinned.cuda(non_blocking=True), 5, torch)
         chan = {"embed_postproc": {"ms": round(ms_e, 4), "h2d_ms_4096d_fp32_batch": round(ms_h, 3),
-                                   "note": "not part of the timed step: the step starts from unit "
-                                           "query vectors resident in HBM"},
+                                   "note": "thr_embed_postproc IS the first kernel of every timed step "
+                                           "(the step starts from the model's 4096-d vectors in HBM); the "
+                                           "H2D copy of that raw batch from pinned memory is quoted "
+                                           "beside it and is not in `value`"},
                 "dense_search_ms": round(ms_d, 3),
-                "bm25": {"ms": round(ms_b, 3), "postings_per_query": round(post / nq, 1),
-                         "algorithmic_GBps": round((post * 12 + nq * 64) / ms_b / 1e6, 1)},
+                "bm25": bm,
                 "graph": {"ms": round(ms_g, 3), "algorithmic_GBps": round(8800 * nq / ms_g / 1e6, 1)},
                 "rrf_ms": round(ms_r, 3),
                 "maxsim": {"ms": round(ms_m, 3), "algorithmic_GBps": round(by_m / ms_m / 1e6, 1),
@@ -402,16 +455,23 @@ def main():
         from oracle import thr_oracle as O
         torch.set_num_threads(os.cpu_count() or 1)
         nq_cpu = min(args.cpu_queries, nq)
-        dn = index.dnorm.cpu().numpy()
+        # everything the CPU leg uses is computed on the CPU: the row norms (index set-up, not
+        # timed on either side) and the post-processed query vectors (timed, as on the GPU)
+        dn = CO.doc_norms(docs)
+        norms_equal = bool(np.array_equal(index.dnorm.cpu().numpy(), dn))
         t0 = time.perf_counter()
-        Sc, Ic = O.dense_topk_fast(docs, queries[:nq_cpu], 100, dnorm=dn)
+        q_cpu = O.embed_postproc_batch(raw[:nq_cpu], args.dim)
+        Sc, Ic = O.dense_topk_fast(docs, q_cpu, 100, dnorm=dn)
         fused_ids = [O.fused_topk_ids(None, list(i), None, args.top_k)[0] for i in Ic]
         cpu_s = time.perf_counter() - t0
         cpu = {"value": round(nq_cpu / cpu_s, 2), "unit": "queries/s", "cores": os.cpu_count(),
                "kind": "port",
                "sample": f"{nq_cpu} of the {nq} queries over the full "
-                         f"{args.docs}x{args.dim} corpus (fp32 BLAS shortlist + fp64 rescoring "
-                         f"+ RRF), {cpu_s:.1f} s"}
+                         f"{args.docs}x{args.dim} corpus (embedding post-processing + fp32 BLAS shortlist + "
+                         f"fp64 rescoring + RRF), {cpu_s:.1f} s; row norms computed on the CPU beforehand",
+               "gpu_inputs_equal_the_cpu_ones": {
+                   "thr_doc_norms_bits": norms_equal,
+                   "thr_embed_postproc_bits": bool(np.array_equal(qd[:nq_cpu].cpu().numpy(), q_cpu))}}
         ids = head_ids.cpu().numpy()
         if head_cfg == "dense":
             same = sum(list(ids[i]) == fused_ids[i] for i in range(nq_cpu))
@@ -481,7 +541,12 @@ def main():
                        "parallelism": (f"doc-shard x{doc_shards}" + (f" x {n_replicas} replicas"
                                        if n_replicas > 1 else "")) if world > 1 else "single GPU",
                        "collective_backend": backend, "world_size_seen": dist.get_world_size() if world > 1 else 1,
-                       "rescued_queries": rescued, "input_gen_s": round(gen_s, 1)},
+                       "rescued_queries": rescued, "input_gen_s": round(gen_s, 1),
+                       "step": "thr_embed_postproc of the 4096-d query batch (resident in HBM) -> dense top-100"
+                               + ("" if head_cfg == "dense" else " + BM25 top-50" + (" + graph top-50" if head_cfg.startswith("triple") else ""))
+                               + " -> weighted RRF -> fused top-10" + (" of the MaxSim-reranked top-100" if head_cfg == "triple_rerank" else ""),
+                       "lexical_mix": args.lexical_mix if head_cfg != "dense" else None,
+                       "per_rank_ms": per_rank},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cfg_out:
