@@ -257,6 +257,37 @@ int thr_rrf_fuse(const int64_t *lex_ids, int n_lex, const int64_t *sem_ids, int 
                  double *out_scores /* [nq,top_k] */, int32_t *out_ranks /* [nq,top_k,3] or NULL */,
                  int32_t *out_counts, thr_stream_t stream);
 
+/* f3  the standalone package's RRFFusion on the device (second fusion variant of the reference,
+ * triple-hybrid-rag/src/triple_hybrid_rag/core/fusion.py): a channel's table value is
+ * ``weight * (1.0 / (60 + rank))`` of the id's LAST rank (:167-185).  two_channels == 0: ``fuse``
+ * (:52-165) -- the value is added once per OCCURRENCE of the id in the channel, channels in the
+ * order lexical, semantic, graph; two_channels != 0: ``fuse_two_channels(a, b, wa, wb)``
+ * (:249-292) with a in the lexical slot and b in the semantic slot (a's value assigned once, b's
+ * added per occurrence; graph_ids must be NULL).  Sighting order and stable descending sort as in
+ * thr_rrf_fuse; out_ranks (optional) feeds thr_fuse_post. */
+int thr_rrf_fuse_standalone(const int64_t *lex_ids, int n_lex, const int64_t *sem_ids, int n_sem,
+                            const int64_t *graph_ids, int n_graph, int n_queries, double w_lex,
+                            double w_sem, double w_graph, int two_channels, int top_k,
+                            int64_t *out_ids, double *out_scores, int32_t *out_ranks /* or NULL */,
+                            int32_t *out_counts, thr_stream_t stream);
+/* What RRFFusion.fuse does after its sort, and normalize_scores, for a batch of fused lists
+ * [n_queries, n] (best first; counts[q] rows valid, NULL = n):
+ *   safety_threshold > 0  keep rows whose best channel score max(semantic or 0, lexical or 0,
+ *                         graph or 0) is >= it (fusion.py:187-216); the channel scores are read
+ *                         at the id's last rank: ranks [n_queries, n, 3] from thr_rrf_fuse*,
+ *                         *_scores [n_queries, n_*] float64 (NULL = channel absent);
+ *   denoise != 0          with >= 3 rows left: cut = numpy.percentile(scores, 100 * quantile) with
+ *                         numpy's linear interpolation, keep scores >= cut (:218-247); the caller
+ *                         passes quantile = ((1 - denoise_alpha) * 100) / 100;
+ *   top_k > 0             the first top_k of what is left;
+ *   normalize != 0        min-max to [0, 1] over what is left, 1.0 when all equal (:294-318).
+ * out_* are [n_queries, n] (ids -1 / scores -inf past out_counts[q]). */
+int thr_fuse_post(const int64_t *ids, const double *scores, const int32_t *ranks,
+                  const int32_t *counts, int n_queries, int n, const double *lex_scores, int n_lex,
+                  const double *sem_scores, int n_sem, const double *graph_scores, int n_graph,
+                  double safety_threshold, int denoise, double quantile, int normalize, int top_k,
+                  int64_t *out_ids, double *out_scores, int32_t *out_counts, thr_stream_t stream);
+
 /* a8  late-interaction rerank: MaxSim(q, c) = sum_i max_j <q_i, d_cj> with
  * float16 token matrices on MFMA (float32 accumulate).
  * Stands where Qwen3VLReranker._rerank_batch_native is called,

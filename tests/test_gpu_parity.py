@@ -1359,3 +1359,160 @@ def test_bench_multi_rank_control_flow():
         assert rec["config"]["collective_backend"] == "gloo" and rec["config"]["world_size_seen"] == 2
         assert rec["config"]["pipeline"] == (cfg[1] if cfg else "dense")
         port += 1
+
+
+def test_tool_layer_over_a_gpu_index_client(T, golden):
+    """8f.2 on the GPU: the agent tool ``search_knowledge_base()`` (reference
+    src/voice_agent/tools/crm_knowledge.py:26-182; tests/test_rag2_tool_connection.py:75-330) with
+    NOTHING injected -- tenant discovery through the registered GpuIndexClient, the default
+    embedder / planner, RAG2Retriever.retrieve over the kernels, MaxSim rerank -- returns the
+    dict schema of tests/golden/tool_layer.json with the oracle pipeline's chunks, ranks and
+    rounded scores; refusals and a category (= collection) filter map as in the reference."""
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd import backend
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    from triple_hybrid_rag_amd.config import SETTINGS
+    from triple_hybrid_rag_amd.rag2.embedder import HashEmbedder
+    from triple_hybrid_rag_amd.tools import crm_knowledge as crm
+
+    n, d = 20000, 768
+    x = synth.dense_rows(0, n, d)
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    dtok = synth.doc_tokens(0, n, 32, 64)
+    idx = (T.GpuIndex().set_dense(x)
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl).set_tokens(dtok))
+    store = CorpusStore.synthetic(n, vocab_size=v)
+    store.collections = ["faq" if i % 5 == 0 else "pricing" for i in range(n)]
+
+    class TokEmb:
+        def embed_query_tokens(self, query):
+            return synth.query_tokens(1, 32, 64)[0]
+
+    client = GpuIndexClient(idx, store, org_id="org-7", token_embedder=TokEmb())
+    saved = dict(SETTINGS.__dict__)
+    gold = golden("tool_layer.json")
+    ok_keys = set(next(c["out"] for c in gold if c["out"].get("results")).keys())
+    row_keys = set(next(c["out"]["results"][0] for c in gold if c["out"].get("results")).keys())
+    refused_keys = set(next(c["out"] for c in gold if c["out"].get("refused")).keys())
+    try:
+        backend.set_default_client(client)
+        SETTINGS.rag2_enabled = True
+        SETTINGS.rag2_graph_enabled = False
+        SETTINGS.rag2_embed_dim_store = d
+        SETTINGS.rag2_safety_threshold = 0.0
+        SETTINGS.rag2_denoise_alpha = 0.0
+        text = "t100 t2000 t77"
+        out = crm.search_knowledge_base(text, None, 5)
+        assert set(out.keys()) == ok_keys and out["success"] and out["search_type"] == "rag2_triple_hybrid"
+        assert out["query"] == text and out["category"] is None and out["result_count"] == len(out["results"]) == 5
+        assert all(set(r.keys()) == row_keys for r in out["results"])
+        # (the keys retrieve() sets, reference rag2/retrieval.py:153-191)
+        assert set(out["timings_ms"]) == {"planning", "retrieval", "fusion", "expansion", "rerank", "safety"}
+        assert all(isinstance(t, float) and t >= 0 for t in out["timings_ms"].values())
+        # the oracle pipeline for the same query: dense + BM25 -> RRF -> top 20 -> MaxSim order
+        qv = np.asarray(HashEmbedder(store_dim=d).embed_query(text), dtype=np.float32)
+        _, Id, _ = CO.dense_topk_exact(x, qv[None], 100)
+        tids = [store.vocab[w] for w in text.split()]
+        _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [tids], n, 50)
+        f20, s20 = O.fused_topk_ids(list(Il[0]), list(Id[0]), None, SETTINGS.rag2_rerank_top_k)
+        ms = CO.maxsim(synth.query_tokens(1, 32, 64), dtok, np.array([f20], dtype=np.int32))[0] / 32.0
+        order = O.rerank_order([float(s) for s in ms])[:5]
+        gaps = np.abs(np.diff(np.sort(ms)[::-1][:6]))
+        if gaps.min() > 1e-4:   # (the order is pinned wherever the oracle's scores are apart)
+            assert [r["chunk_id"] for r in out["results"]] == [f"c{f20[j]}" for j in order]
+        for pos, r in enumerate(out["results"]):
+            doc = int(r["chunk_id"][1:])
+            j = f20.index(doc)
+            assert r["relevance_rank"] == pos + 1 and r["parent_id"] == f"p{doc // 4}"
+            assert r["similarity_score"] == round(s20[j], 4)
+            assert abs(r["rerank_score"] - round(float(ms[j]), 4)) <= 1.01e-4
+            assert r["content"] == f"parent text {doc // 4}" and r["title"] == f"Section {doc // 4}"
+            assert r["lexical_rank"] == (list(Il[0]).index(doc) + 1 if doc in Il[0] else None)
+            assert r["semantic_rank"] == (list(Id[0]).index(doc) + 1 if doc in Id[0] else None)
+            assert r["graph_rank"] is None and r["is_table"] is False and r["category"] is None
+        assert abs(out["max_rerank_score"] - round(float(ms.max()), 4)) <= 1.01e-4
+        # category = the collection filter of the RPCs, applied on the device before the ranking
+        faq = crm.search_knowledge_base(text, "faq", 3)
+        assert faq["category"] == "faq" and faq["result_count"] == 3
+        assert all(int(r["chunk_id"][1:]) % 5 == 0 and r["category"] == "faq" for r in faq["results"])
+        # below the threshold -> refusal mapping (success stays True)
+        SETTINGS.rag2_safety_threshold = 0.999
+        ref = crm.search_knowledge_base(text, None, 5)
+        assert set(ref.keys()) == refused_keys and ref["refused"] and ref["success"] and ref["results"] == []
+        assert ref["refusal_reason"].startswith("Max score") and "below threshold 0.999" in ref["refusal_reason"]
+        # the tenant the tool discovers is the index's: another client id sees nothing
+        SETTINGS.rag2_safety_threshold = 0.0
+        other = crm._search_knowledge_base_rag2(text, None, 5, org_id="someone-else")
+        assert other["refused"] and other["refusal_reason"] == "No candidates found"
+        # never raises into the agent
+        backend.set_default_client(None)
+        err = crm.search_knowledge_base(text, None, 5)
+        assert set(err.keys()) == {"error", "query", "category"} and err["error"].startswith("Database error")
+    finally:
+        SETTINGS.__dict__.update(saved)
+        backend.set_default_client(None)
+
+
+def test_standalone_fusion_on_the_device(T, golden):
+    """8f.3: the standalone package's RRFFusion as device ops -- thr_rrf_fuse_standalone (``fuse``
+    and ``fuse_two_channels`` arithmetic: weight * (1 / (60 + rank)), per-occurrence adds) and
+    thr_fuse_post (safety threshold, numpy-percentile denoise, [:top_k], min-max normalise) --
+    against the reference's own outputs (tests/golden/standalone_fusion.json <-
+    triple-hybrid-rag/src/triple_hybrid_rag/core/fusion.py:52-318), bit for bit."""
+    from triple_hybrid_rag_amd.config import RAGConfig
+    from triple_hybrid_rag_amd.core.fusion import RRFFusion
+    g = golden("standalone_fusion.json")
+
+    def table(rows_lists):
+        ids = {}
+        for rows in rows_lists:
+            for r in rows:
+                ids.setdefault(r["chunk_id"], len(ids) + 100)
+        return ids
+
+    def tensors(rows, ids, key):
+        if not rows:
+            return None, None
+        i = torch.tensor([[ids[r["chunk_id"]] for r in rows]], dtype=torch.int64, device="cuda")
+        s = torch.tensor([[float(r.get(key, 0.0)) for r in rows]], dtype=torch.float64, device="cuda")
+        return i, s
+
+    for c in g["fuse"]:
+        ids = table([c["lexical"], c["semantic"], c["graph"]])
+        back = {v: k for k, v in ids.items()}
+        li, ls = tensors(c["lexical"], ids, "lexical_score")
+        si, ss = tensors(c["semantic"], ids, "semantic_score")
+        gi, gs = tensors(c["graph"], ids, "graph_score")
+        fus = RRFFusion(RAGConfig(rag_safety_threshold=c["safety_threshold"],
+                                  rag_denoise_enabled=c["denoise_enabled"],
+                                  rag_denoise_alpha=c["denoise_alpha"]))
+        oi, os_, oc = fus.fuse_batch(li, si, gi, ls, ss, gs, weights=c["weights"], top_k=c["top_k"])
+        m = int(oc[0])
+        assert [back[int(i)] for i in oi[0, :m]] == [r["chunk_id"] for r in c["out"]]
+        assert [float(s) for s in os_[0, :m]] == [r["rrf_score"] for r in c["out"]]
+        assert bool((oi[0, m:] == -1).all())
+    for c in g["two"]:
+        ids = table([c["a"], c["b"]])
+        back = {v: k for k, v in ids.items()}
+        ai, _ = tensors(c["a"], ids, "x")
+        bi, _ = tensors(c["b"], ids, "x")
+        oi, os_, _, oc = T._native.rrf_fuse_standalone(ai, bi, None, c["top_k"] or 256, c["wa"], c["wb"], 0.0,
+                                                       two_channels=True)
+        m = int(oc[0])
+        assert [{"chunk_id": back[int(i)], "rrf_score": float(s)} for i, s in zip(oi[0, :m], os_[0, :m])] == c["out"]
+    for c in g["normalize"]:
+        n = len(c["in"])
+        if n == 0:
+            continue
+        sc = torch.tensor([c["in"]], dtype=torch.float64, device="cuda")
+        di = torch.arange(n, dtype=torch.int64, device="cuda")[None]
+        _, os_, oc = T._native.fuse_post(di, sc, normalize=True)
+        assert int(oc[0]) == n and [float(s) for s in os_[0]] == c["out"]
+    # a batch of lists with padding: every row equals its own one-row call
+    ci = torch.tensor([[5, 9, 7, -1], [3, -1, -1, -1], [8, 6, 4, 2]], dtype=torch.int64, device="cuda")
+    cj = torch.tensor([[9, 1, -1], [3, 2, 1], [-1, -1, -1]], dtype=torch.int64, device="cuda")
+    bi, bs, br, bc = T._native.rrf_fuse_standalone(ci, cj, None, 7, 0.7, 0.8, 1.0)
+    for q in range(3):
+        oi, os_, _, oc = T._native.rrf_fuse_standalone(ci[q:q + 1].contiguous(), cj[q:q + 1].contiguous(), None, 7,
+                                                       0.7, 0.8, 1.0)
+        assert torch.equal(bi[q], oi[0]) and torch.equal(bs[q], os_[0]) and int(bc[q]) == int(oc[0])

@@ -69,6 +69,10 @@ _SIGNATURES = {
                               _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_rrf_fuse": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
                             _vp, _vp, _vp, _vp, _vp]),
+    "thr_rrf_fuse_standalone": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _dbl, _dbl, _dbl, _i32, _i32,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    "thr_fuse_post": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _dbl, _i32,
+                             _dbl, _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_rerank_order": (_i32, [_vp, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "thr_maxsim": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "thr_maxsim_ids": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i32, _vp]),
@@ -503,6 +507,67 @@ def rrf_fuse(lex_ids, sem_ids, graph_ids, top_k: int, w_lex: float = 0.7, w_sem:
                                out_sc.data_ptr(), out_rk.data_ptr() if want_ranks else 0,
                                cnt.data_ptr(), _stream()), "thr_rrf_fuse")
     return out_ids, out_sc, out_rk, cnt
+
+
+def rrf_fuse_standalone(lex_ids, sem_ids, graph_ids, top_k: int, w_lex: float = 0.7, w_sem: float = 0.8,
+                        w_graph: float = 1.0, two_channels: bool = False, want_ranks: bool = True):
+    """The standalone package's RRFFusion.fuse / fuse_two_channels on id lists [nq, n_c] (-1
+    padded) -> (ids i64 [nq, top_k], scores f64, ranks i32 [nq, top_k, 3] or None, counts)."""
+    chans = [lex_ids, sem_ids, graph_ids]
+    ref = next(c for c in chans if c is not None)
+    nq = ref.shape[0]
+    ptrs, widths = [], []
+    for name, c in zip(("lex_ids", "sem_ids", "graph_ids"), chans):
+        if c is None:
+            ptrs.append(0)
+            widths.append(0)
+            continue
+        ptrs.append(_dev(c, torch.int64, name, 2))
+        if c.shape[0] != nq or c.shape[1] > THR_RRF_MAX_PER_CHANNEL:
+            raise NativeError(f"rrf: bad shape for {name}")
+        widths.append(c.shape[1])
+    dev = ref.device
+    out_ids = torch.empty((nq, top_k), dtype=torch.int64, device=dev)
+    out_sc = torch.empty((nq, top_k), dtype=torch.float64, device=dev)
+    out_rk = torch.empty((nq, top_k, 3), dtype=torch.int32, device=dev) if want_ranks else None
+    cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+    _check(load().thr_rrf_fuse_standalone(ptrs[0], widths[0], ptrs[1], widths[1], ptrs[2], widths[2], nq,
+                                          w_lex, w_sem, w_graph, 1 if two_channels else 0, top_k,
+                                          out_ids.data_ptr(), out_sc.data_ptr(),
+                                          out_rk.data_ptr() if want_ranks else 0, cnt.data_ptr(),
+                                          _stream()), "thr_rrf_fuse_standalone")
+    return out_ids, out_sc, out_rk, cnt
+
+
+def fuse_post(ids, scores, ranks=None, counts=None, channel_scores=(None, None, None),
+              safety_threshold: float = 0.0, denoise_quantile: Optional[float] = None,
+              normalize: bool = False, top_k: int = 0):
+    """Safety threshold / percentile denoise / truncation / min-max normalisation of a batch of
+    fused lists (thr_fuse_post).  denoise_quantile = ((1 - alpha) * 100) / 100 or None."""
+    pi = _dev(ids, torch.int64, "ids", 2)
+    ps = _dev(scores, torch.float64, "scores", 2)
+    nq, n = ids.shape
+    if tuple(scores.shape) != (nq, n):
+        raise NativeError("fuse_post: ids / scores shape mismatch")
+    pr = _dev(ranks, torch.int32, "ranks", 3) if ranks is not None else None
+    if ranks is not None and tuple(ranks.shape) != (nq, n, 3):
+        raise NativeError("fuse_post: ranks must be [nq, n, 3]")
+    pc = _dev(counts, torch.int32, "counts", 1) if counts is not None else None
+    cp, cw = [], []
+    for name, c in zip(("lex_scores", "sem_scores", "graph_scores"), channel_scores):
+        cp.append(_dev(c, torch.float64, name, 2) if c is not None else None)
+        cw.append(c.shape[1] if c is not None else 0)
+        if c is not None and c.shape[0] != nq:
+            raise NativeError(f"fuse_post: bad shape for {name}")
+    out_ids = torch.empty_like(ids)
+    out_sc = torch.empty_like(scores)
+    out_c = torch.empty(nq, dtype=torch.int32, device=ids.device)
+    _check(load().thr_fuse_post(pi, ps, pr, pc, nq, n, cp[0], cw[0], cp[1], cw[1], cp[2], cw[2],
+                                float(safety_threshold), 0 if denoise_quantile is None else 1,
+                                float(denoise_quantile or 0.0), 1 if normalize else 0, int(top_k),
+                                out_ids.data_ptr(), out_sc.data_ptr(), out_c.data_ptr(), _stream()),
+           "thr_fuse_post")
+    return out_ids, out_sc, out_c
 
 
 # --------------------------------------------------------------------- a8

@@ -105,6 +105,26 @@ class RRFFusion:
         out = [hit for _, hit in ordered]
         return out[:top_k] if top_k else out
 
+    def fuse_batch(self, lexical_ids, semantic_ids, graph_ids, lexical_scores=None, semantic_scores=None,
+                   graph_scores=None, weights: Optional[Dict[str, float]] = None,
+                   top_k: Optional[int] = None, normalize: bool = False):
+        """``fuse`` for a BATCH of queries on the device (thr_rrf_fuse_standalone + thr_fuse_post):
+        id tensors int64 [nq, n_c] (best first, -1 padded; None = channel absent), channel score
+        tensors float64 [nq, n_c] (needed for the safety threshold).  Same arithmetic as ``fuse``
+        row by row: table value weight * (1 / (60 + rank)), safety threshold, percentile denoise,
+        [:top_k]; ``normalize`` = normalize_scores on the result.  -> (ids, scores, counts)."""
+        from .. import _native as N
+        w = dict(self.default_weights)
+        w.update(weights or {})
+        width = sum(t.shape[1] for t in (lexical_ids, semantic_ids, graph_ids) if t is not None)
+        ids, sc, rk, cnt = N.rrf_fuse_standalone(lexical_ids, semantic_ids, graph_ids, width,
+                                                 w["lexical"], w["semantic"], w["graph"])
+        q = None
+        if self.denoise_enabled:
+            q = float(np.true_divide((1 - self.denoise_alpha) * 100, 100))
+        return N.fuse_post(ids, sc, rk, cnt, (lexical_scores, semantic_scores, graph_scores),
+                           self.safety_threshold, q, normalize, top_k or 0)
+
     def normalize_scores(self, results: List[SearchResult], score_field: str = "final_score"
                          ) -> List[SearchResult]:
         if not results:
