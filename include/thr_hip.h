@@ -199,7 +199,8 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
                     const float *doclen, const double *idf, double avgdl, double k1, double b,
                     int64_t n_vocab, int64_t nnz, double *term_ub /* [V] */,
                     double *block_ub /* [thr_bm25_block_count(nnz)] */, thr_stream_t stream);
-/* term ids outside [0, n_vocab) are ignored (no postings).  term_ub / block_ub (or NULL: score
+/* term ids outside [0, n_vocab) have no postings: the OR form ignores them, with conjunctive != 0 a
+ * non-negative one makes the query unsatisfiable (empty result, as the SQL AND would give).  term_ub / block_ub (or NULL: score
  * every posting): a doc whose bound cannot beat the running k-th best score is dropped before its
  * term frequencies are fetched -- same results, bit for bit.  conjunctive != 0: only docs that
  * hold EVERY query term (the reference's plainto_tsquery is an AND, rag2_schema.sql:365; the

@@ -47,7 +47,10 @@ def batch_queries(n: int, n_docs: int):
             for _ in range(n)]
 
 
-async def main() -> int:
+async def main(argv=None, make_client=None, out=None) -> int:
+    """``make_client`` (n_docs, dim, org_id) -> backend: the GPU index by default; the CPU leg of
+    BASELINE.json configs[0] (tests/oracle_cli.py) passes the oracle-backed one.  ``out``: a
+    list that receives what --json would print (tests)."""
     ap = argparse.ArgumentParser(description="RAG 2.0 Retrieval Test CLI (MI355X index)")
     ap.add_argument("--query", "-q")
     ap.add_argument("--batch", type=int, default=0,
@@ -62,7 +65,7 @@ async def main() -> int:
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--docs", type=int, default=10_000)
     ap.add_argument("--dim", type=int, default=768)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from triple_hybrid_rag_amd.config import SETTINGS
     from triple_hybrid_rag_amd.rag2.embedder import HashEmbedder
@@ -80,7 +83,7 @@ async def main() -> int:
                               graph_enabled=args.graph)
     if not args.query and not args.batch:
         ap.error("--query or --batch is required")
-    retriever._supabase = build_client(args.docs, args.dim, args.org_id)
+    retriever._supabase = (make_client or build_client)(args.docs, args.dim, args.org_id)
 
     def as_json(result):   # the reference's --json keys (scripts/test_rag2.py:214-235)
         return {"success": result.success, "refused": result.refused,
@@ -92,15 +95,20 @@ async def main() -> int:
                 "timings": result.timings}
 
     if args.batch:
-        out = []
+        rows = []
         for text in batch_queries(args.batch, args.docs):
             r = await retriever.retrieve(query=text, collection=args.collection, top_k=args.top_k)
-            out.append({"query": text, **as_json(r)})
-        print(json.dumps(out))
+            rows.append({"query": text, **as_json(r)})
+        if out is not None:
+            out.extend(rows)
+        else:
+            print(json.dumps(rows))
         return 0
     result = await retriever.retrieve(query=args.query, collection=args.collection,
                                       top_k=args.top_k)
-    if args.json:
+    if out is not None:
+        out.append(as_json(result))
+    elif args.json:
         print(json.dumps(as_json(result), indent=2))
     else:
         print(f"success={result.success} refused={result.refused} reason={result.refusal_reason}")

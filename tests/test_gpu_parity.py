@@ -350,6 +350,8 @@ def test_bm25_pruning_and_filters_stay_exact(T):
     S, I, cnt = idx.bm25_search(qd, 50, conjunctive=True)
     assert_topk_equal(S, I, cnt, Sa, Ia, [len(s) for s in Sa], "bm25 AND")
     assert len(Ia[0]) > 0 and len(Ia[0]) <= len(Ie[0])
+    # an id outside the vocabulary: ignored by the OR form, unsatisfiable in the AND form
+    assert len(Ie[2]) == 50 and len(Ia[2]) == 0 and int(cnt[2]) == 0
     qc = np.full(48, -1, dtype=np.int32)
     qc[0::3], qc[1::3] = 7, 60                                    # thin, fat, unfiltered
     qc[5] = 12345                                                 # a collection no doc is in
@@ -442,6 +444,12 @@ def test_backend_rpcs_filter_by_collection_on_device(T):
     _, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [list(top)], n, 30,
                         conjunctive=True)
     assert [int(r["child_id"][1:]) for r in rows_and] == list(Ia[0])
+    # a token no chunk holds: the SQL AND returns no rows; the OR form ranks on the known terms
+    q_oov = {"p_org_id": "org", "p_query": text + " palavradesconhecida", "p_limit": 30, "p_collection": None}
+    assert client_and.rpc("rag2_lexical_search", q_oov).execute().data == []
+    rows_or = client.rpc("rag2_lexical_search", q_oov).execute().data
+    _, Io = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, [list(top)], n, 30)
+    assert [int(r["child_id"][1:]) for r in rows_or] == list(Io[0])
 
 
 def test_graph_matches_oracle(T):
@@ -1293,6 +1301,14 @@ def test_cli_config0_100_queries_match_the_oracle_pipeline(T):
     assert set(res[0]) == {"query", "success", "refused", "refusal_reason", "max_score", "contexts", "timings"}
     assert set(res[0]["contexts"][0]) == {"child_id", "document_id", "page", "rrf_score", "rerank_score",
                                           "text", "section"}
+    # the CPU leg of configs[0]: the same command line over the oracle-backed client -- same
+    # contexts, same float64 RRF scores, query by query (recall@k = 1, order identical)
+    from tests import oracle_cli
+    rc, cpu = oracle_cli.run(["--batch", "100", "--org-id", "org_1", "--top-k", str(top_k), "--graph", "--json",
+                              "--docs", str(n)])
+    assert rc == 0 and [r["query"] for r in cpu] == [r["query"] for r in res]
+    for a, b in zip(res, cpu):
+        assert a["contexts"] == b["contexts"] and (a["success"], a["refused"]) == (b["success"], b["refused"])
     # the oracle pipeline
     x = synth.dense_rows(0, n, d)
     csr, idf, avgdl, v = lexical_fixture(T, n)

@@ -254,11 +254,19 @@ class GpuIndexClient:
 
     def _lexical(self, query: str, limit: int, collection):
         terms: List[int] = []
+        unknown = False
         for tok in tokenize(query):
             t = self.store.vocab.get(tok)
-            if t is not None and t not in terms:
+            if t is None:
+                unknown = True
+            elif t not in terms:
                 terms.append(t)
         if not terms or self.index.lex is None:
+            return []
+        # AND semantics (plainto_tsquery, rag2_schema.sql:365): a token no chunk holds, or a term
+        # the kernel's term list would have to drop, makes the conjunction unsatisfiable -- the
+        # SQL returns no rows, so does this (the OR form just ignores what it does not know)
+        if self.lexical_and and (unknown or len(terms) > N.THR_BM25_MAX_TERMS):
             return []
         terms = terms[: N.THR_BM25_MAX_TERMS]
         qt = torch.tensor([terms], dtype=torch.int32, device=self.index.device)

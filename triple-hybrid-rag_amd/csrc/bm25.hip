@@ -133,7 +133,7 @@ __device__ __forceinline__ int bm_slices(long long tot, long long target) {
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot,
+    int nq, int mt, int cap, int conjunctive, int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
     __shared__ int red[PLAN_THREADS];
@@ -143,14 +143,17 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     for (int q = q0; q < q1; ++q) {
         int nt = 0, lng = 0;
         long long tot = 0, best = -1;
+        bool dead = false;   // AND mode: a term outside the vocabulary is held by no doc
         for (int j = 0; j < mt; ++j) {
             const int term = query_terms[(int64_t)q * mt + j];
+            if (term >= n_vocab && conjunctive) dead = true;
             if (term < 0 || term >= n_vocab) continue;   // padding / unknown term: no postings
             const long long len = rowptr[term + 1] - rowptr[term];
             if (len > best) { best = len; lng = nt; }
             q_terms[(int64_t)q * mt + nt++] = term;
             tot += len;
         }
+        if (dead) nt = 0, tot = 0;   // (nothing to score: the item writes an empty list)
         q_nt[q] = nt;
         q_long[q] = lng;
         q_tot[q] = tot;
@@ -883,7 +886,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, ctl, q_tot, q_nt, q_S, q_item0, q_long, q_terms, items);
+                       n_queries, max_terms, L.cap, conjunctive, ctl, q_tot, q_nt, q_S, q_item0, q_long, q_terms,
+                       items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
                        rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, ipos);
