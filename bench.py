@@ -437,11 +437,14 @@ def main():
         retr._supabase = client
         text = "t100 t2000 t77" if need_lex else ""
         ts = []
-        for i in range(33):
+        loop = asyncio.new_event_loop()   # one loop for all the calls, as the reference's tool layer
+        for i in range(33):               # keeps one (tools/crm_knowledge.py:111-124)
             t1 = time.perf_counter()
-            out = asyncio.run(retr.retrieve(text, top_k=args.top_k, skip_planning=True, skip_rerank=True))
+            out = loop.run_until_complete(retr.retrieve(text, top_k=args.top_k, skip_planning=True,
+                                                        skip_rerank=True))
             if i >= 3:
                 ts.append((time.perf_counter() - t1) * 1e3)
+        loop.close()
         latency["dropin_retrieve_ms"] = {"p50": round(float(np.percentile(ts, 50)), 3),
                                          "p95": round(float(np.percentile(ts, 95)), 3),
                                          "contexts": len(out.contexts),

@@ -208,8 +208,9 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * [nq] (both or neither; query_coll -1 = unfiltered): only docs of the query's collection are
  * ranked, BEFORE the top-k -- ``AND (p_collection IS NULL OR d.collection = p_collection)``,
  * rag2_schema.sql:368-373. */
-/* Work decomposition (ABI 5): queries whose lists hold >= 24576 postings are cut into doc-range
- * slices (up to 128, equal shares of the query's longest list), every slice is a work item of a
+/* Work decomposition (ABI 5): queries whose lists hold more than one slice's postings (24576 when
+ * the batch fills the chip, down to 8192 when it does not -- a one-query call spreads over several
+ * workgroups) are cut into doc-range slices (up to 128, equal shares of the query's longest list), every slice is a work item of a
  * persistent grid, the slices of a query share the pruning threshold through a device-side
  * atomic max and are merged at the end -- a stop-word query is the job of many workgroups, not
  * of one.  ``workspace`` >= thr_bm25_workspace_bytes(n_queries, max_terms, k): item list, slice

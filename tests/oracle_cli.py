@@ -56,7 +56,9 @@ def oracle_client(n_docs: int, dim: int, org_id: str):
             S, I, cnt = CO.dense_topk_exact(x, q, min(256, limit), dnorm=dn)
             return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "similarity", limit)
 
-        def _lexical(self, query, limit, collection):
+        defers_readback = False
+
+        def _lexical(self, query, limit, collection, defer=False):
             terms = []
             for tok in tokenize(query):
                 t = store.vocab.get(tok)
@@ -78,8 +80,13 @@ def oracle_client(n_docs: int, dim: int, org_id: str):
 
 def run(argv):
     """-> the list of result dicts the CLI's --json would print."""
+    from triple_hybrid_rag_amd.config import SETTINGS
+    saved = dict(SETTINGS.__dict__)   # (the CLI sets the thresholds / switches of its run globally)
     out = []
-    rc = asyncio.run(_cli().main(argv, make_client=oracle_client, out=out))
+    try:
+        rc = asyncio.run(_cli().main(argv, make_client=oracle_client, out=out))
+    finally:
+        SETTINGS.__dict__.update(saved)
     return rc, out
 
 

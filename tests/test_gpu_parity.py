@@ -1413,6 +1413,7 @@ def test_tool_layer_over_a_gpu_index_client(T, golden):
     try:
         backend.set_default_client(client)
         SETTINGS.rag2_enabled = True
+        SETTINGS.rag2_rerank_enabled = True
         SETTINGS.rag2_graph_enabled = False
         SETTINGS.rag2_embed_dim_store = d
         SETTINGS.rag2_safety_threshold = 0.0

@@ -431,8 +431,13 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
 
 
 # --------------------------------------------------------------------- a4
+def graph_workspace_bytes(n_queries: int, n_entities: int) -> int:
+    return int(load().thr_graph_workspace_bytes(n_queries, n_entities))
+
+
 def graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, query_seeds, hops: int,
-               k: int, chunk_base: int, n_chunks: int, transposed=None):
+               k: int, chunk_base: int, n_chunks: int, transposed=None,
+               workspace: Optional[torch.Tensor] = None):
     """-> (scores, ids, counts, flags).  ``transposed`` = (tmen_rowptr i64 [n_chunks+1], tmen_ent
     i32, tmen_conf f32) from ``graph_transpose_mentions`` enables the capacity-free third tier."""
     per = _dev(ent_rowptr, torch.int64, "ent_rowptr", 1)
@@ -455,7 +460,9 @@ def graph_topk(ent_rowptr, ent_col, men_rowptr, men_chunk, men_conf, query_seeds
     if ms > THR_GRAPH_MAX_SEEDS or k > THR_TOPK_MAX:
         raise NativeError("graph: too many seeds per query or k too large")
     need = int(load().thr_graph_workspace_bytes(nq, n_ent if transposed is not None else 0))
-    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=ent_rowptr.device)
+    ws = workspace
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(max(need, 8), dtype=torch.uint8, device=ent_rowptr.device)
     S, I, cnt, flg = _alloc_out(nq, k, ent_rowptr.device)
     _check(load().thr_graph_topk(per, pec, n_ent, pmr, pmc, pmw, ptr, pte, ptw, chunk_base,
                                  n_chunks, pqs, nq, ms, hops, k, S.data_ptr(), I.data_ptr(),

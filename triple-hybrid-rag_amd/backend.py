@@ -90,6 +90,46 @@ class _Reply:
         return self
 
 
+class LazyRows(list):
+    """Rows of an RPC whose kernels are in flight: the read-back happens when the rows are first
+    looked at, so the caller can issue its next RPC in the meantime.  A failure of the deferred
+    part degrades to an empty channel, as a failing RPC does in the reference (retrieval.py:291)."""
+
+    def __init__(self, fetch):
+        super().__init__()
+        self._fetch = fetch
+
+    def _ready(self):
+        fetch, self._fetch = self._fetch, None
+        if fetch is not None:
+            try:
+                super().extend(fetch())
+            except Exception as exc:  # noqa: BLE001
+                import logging
+                logging.getLogger(__name__).warning("deferred RPC failed: %s", exc)
+
+    def __iter__(self):
+        self._ready()
+        return super().__iter__()
+
+    def __len__(self):
+        self._ready()
+        return super().__len__()
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def __getitem__(self, i):
+        self._ready()
+        return super().__getitem__(i)
+
+    def __eq__(self, other):
+        self._ready()
+        return list(self) == other
+
+    __hash__ = None
+
+
 class _TableQuery:
     def __init__(self, fetch):
         self._fetch = fetch
@@ -120,6 +160,8 @@ class _TableQuery:
 class GpuIndexClient:
     """Supabase-shaped facade over (GpuIndex, CorpusStore)."""
 
+    defers_readback = True   # rag2_lexical_search honours ``_defer`` (see _lexical)
+
     def __init__(self, index: GpuIndex, store: CorpusStore, org_id: Optional[str] = None,
                  token_embedder: Any = None, lexical_and: bool = False,
                  image_index: Optional[GpuIndex] = None, image_rows: Any = None):
@@ -139,6 +181,7 @@ class GpuIndexClient:
         self.store = store
         self.org_id = org_id
         self.token_embedder = token_embedder
+        self._pin: Dict[Any, list] = {}   # reusable pinned staging buffers (one query per call)
         # collection names -> ids; the filter itself runs on the device, before the ranking
         self._coll_id: Dict[str, int] = {}
         if store.collections is not None:
@@ -164,7 +207,7 @@ class GpuIndexClient:
                                          params.get("p_collection")))
         if name == "rag2_lexical_search":
             return _Reply(self._lexical(params["p_query"], int(params.get("p_limit", 50)),
-                                        params.get("p_collection")))
+                                        params.get("p_collection"), defer=bool(params.get("_defer"))))
         if name == "rag2_hybrid_rrf_search":
             return _Reply(self._hybrid_rrf(params))
         if name == "kb_chunks_vector_search":   # legacy RAG 1.0 (20260113_halfvec_4000.sql:70-105)
@@ -235,24 +278,65 @@ class GpuIndexClient:
             rows.append(row)
         return rows
 
+    # ---- one query per call: the host side is most of the latency, so every RPC does ONE pinned
+    # upload and ONE read-back (scores and ids are the two halves of one [2, 1, k] tile) ----
+    def _upload(self, values, dtype, device) -> torch.Tensor:
+        """[1, n] device tensor of ``values`` through a reusable pinned buffer."""
+        a = np.asarray(values, dtype=np.float32 if dtype == torch.float32 else np.int32).reshape(1, -1)
+        key = (dtype, a.shape[1])
+        slot = self._pin.get(key)
+        if slot is None:
+            slot = self._pin[key] = [torch.empty((1, a.shape[1]), dtype=dtype).pin_memory(), None]
+        buf, ev = slot
+        if ev is not None:
+            ev.synchronize()            # the previous copy out of this buffer has left the host
+        buf.numpy()[...] = a
+        out = buf.to(device, non_blocking=True)
+        if device.type == "cuda":
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        return out
+
+    @staticmethod
+    def _download(S: torch.Tensor, I: torch.Tensor):
+        """(scores list, ids list without the -1 padding) in one device-to-host copy."""
+        k = I.shape[1]
+        if (S.dtype == torch.float64 and S.untyped_storage().data_ptr() == I.untyped_storage().data_ptr()
+                and I.data_ptr() - S.data_ptr() == k * 8 and S.shape[0] == 1):
+            both = torch.as_strided(S.view(torch.int64), (2, k), (k, 1)).cpu()
+            scores, ids = both[0].view(torch.float64).tolist(), both[1].tolist()
+        else:
+            scores, ids = S[0].tolist(), I[0].tolist()
+        n = 0
+        while n < k and ids[n] >= 0:
+            n += 1
+        return scores[:n], ids[:n]
+
     def _rows(self, ids, scores, count, score_key, limit):
+        """RPC result rows (the columns of rag2_schema.sql:350-358 / :386-394), best first."""
+        st = self.store
+        base, cid, pid, did = st.doc_base, st.child_ids, st.parent_ids, st.document_ids
+        txt, pg, md = st.texts, st.pages, st.modalities
         out = []
         for gid, sc in zip(ids[:min(count, limit)], scores[:count]):
-            row = self.store.result_row(int(gid) - self.store.doc_base)
-            row[score_key] = float(sc)
-            out.append(row)
+            i = gid - base
+            out.append({"child_id": cid[i], "parent_id": pid[i], "document_id": did[i], "text": txt[i],
+                        "page": pg[i], "modality": md[i], score_key: sc})
         return out
 
     def _semantic(self, embedding, limit: int, collection):
-        q = torch.tensor([list(map(float, embedding))], dtype=torch.float32,
-                         device=self.index.device)
-        if q.shape[1] != self.index.dim:
-            raise ValueError(f"embedding has {q.shape[1]} dims, index has {self.index.dim}")
+        if len(embedding) != self.index.dim:
+            raise ValueError(f"embedding has {len(embedding)} dims, index has {self.index.dim}")
+        q = self._upload(embedding, torch.float32, self.index.device)
         k = min(N.THR_DENSE_MAX_K, limit)
-        S, I, cnt, _ = self.index.dense_search(q, k, collections=self._qcoll(collection))
-        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "similarity", limit)
+        S, I, _, _ = self.index.dense_search(q, k, collections=self._qcoll(collection), sync=False)
+        scores, ids = self._download(S, I)
+        return self._rows(ids, scores, len(ids), "similarity", limit)
 
-    def _lexical(self, query: str, limit: int, collection):
+    def _lexical(self, query: str, limit: int, collection, defer: bool = False):
+        """defer=True (``_defer`` in the RPC's params; RAG2Retriever sets it): the kernels are
+        enqueued on the index's side stream and the rows are read back when first looked at --
+        the retriever issues its semantic RPC in between, and the two channels overlap."""
         terms: List[int] = []
         unknown = False
         for tok in tokenize(query):
@@ -269,11 +353,29 @@ class GpuIndexClient:
         if self.lexical_and and (unknown or len(terms) > N.THR_BM25_MAX_TERMS):
             return []
         terms = terms[: N.THR_BM25_MAX_TERMS]
-        qt = torch.tensor([terms], dtype=torch.int32, device=self.index.device)
+        # (fixed width: one pinned buffer, one workspace size, whatever the number of terms)
+        qt = self._upload(terms + [-1] * (N.THR_BM25_MAX_TERMS - len(terms)), torch.int32, self.index.device)
         k = min(N.THR_TOPK_MAX, limit)
-        S, I, cnt = self.index.bm25_search(qt, k, collections=self._qcoll(collection),
-                                           conjunctive=self.lexical_and)
-        return self._rows(I[0].tolist(), S[0].tolist(), int(cnt[0]), "rank", limit)
+        if not defer or self.index.device.type != "cuda":
+            S, I, _ = self.index.bm25_search(qt, k, collections=self._qcoll(collection),
+                                             conjunctive=self.lexical_and)
+            scores, ids = self._download(S, I)
+            return self._rows(ids, scores, len(ids), "rank", limit)
+        side = self.index.side_stream()
+        main = torch.cuda.current_stream(self.index.device)
+        side.wait_stream(main)              # the upload was enqueued on the main stream
+        qc = self._qcoll(collection)
+        with torch.cuda.stream(side):
+            S, I, _ = self.index.bm25_search(qt, k, collections=qc, conjunctive=self.lexical_and)
+        for t in (qt, qc):
+            if t is not None:
+                t.record_stream(side)
+
+        def fetch():
+            with torch.cuda.stream(side):   # the copy is ordered after the kernels on their stream
+                scores, ids = self._download(S, I)
+            return self._rows(ids, scores, len(ids), "rank", limit)
+        return LazyRows(fetch)
 
     # -------------------------------------------------------------- tables
     def table(self, name: str) -> _TableQuery:
@@ -297,18 +399,49 @@ class GpuIndexClient:
         raise ValueError(f"table {name!r} is not served by the GPU index")
 
     # --------------------------------------------------------------- graph
+    def _entity_index(self):
+        """Trigram index of the lower-cased entity names, built on first use: (sorted trigram
+        codes, entity of each) -- a keyword of >= 3 characters is looked up by intersecting the
+        entity lists of its trigrams instead of scanning every name (2.5M names at 10M docs)."""
+        if getattr(self, "_tri", None) is None:
+            names = [nm.lower() for nm in self.store.entity_names]
+            cp = np.frombuffer("\x00".join(names).encode("utf-32-le"), dtype=np.uint32).astype(np.int64)
+            ent = np.repeat(np.arange(len(names), dtype=np.int64),
+                            np.fromiter((len(nm) + 1 for nm in names), dtype=np.int64, count=len(names)))[:len(cp)]
+            ok = np.ones(max(len(cp) - 2, 0), dtype=bool)
+            for off in range(3):   # a trigram must not straddle the separator between two names
+                ok &= cp[off:len(cp) - 2 + off] != 0
+            code = (cp[:-2] * 1114112 + cp[1:-1]) * 1114112 + cp[2:] if len(cp) > 2 else cp[:0]
+            code, e3 = code[ok], ent[:len(ok)][ok]
+            order = np.argsort(code, kind="stable")      # (entities stay ascending inside a trigram)
+            self._tri = (code[order], e3[order], names)
+        return self._tri
+
     def find_entities(self, keywords: List[str], limit: int = 20) -> List[int]:
         """Entity ids whose name contains a keyword (ILIKE '%kw%'), at most 5 keywords and
-        limit // len(keywords) entities each (graph_search.py:161-170)."""
-        names = self.store.entity_names
-        if not keywords or not names:
+        limit // len(keywords) entities each, in ascending entity order (graph_search.py:161-170)."""
+        if not keywords or not self.store.entity_names:
             return []
+        codes, ents, names = self._entity_index()
         per = max(1, limit // len(keywords))
         found: List[int] = []
         for kw in keywords[:5]:
             needle, hits = kw.lower(), 0
-            for e, name in enumerate(names):
-                if needle in name.lower():
+            if len(needle) >= 3:
+                cp = np.frombuffer(needle.encode("utf-32-le"), dtype=np.uint32).astype(np.int64)
+                tri = np.unique((cp[:-2] * 1114112 + cp[1:-1]) * 1114112 + cp[2:])
+                lo, hi = np.searchsorted(codes, tri, "left"), np.searchsorted(codes, tri, "right")
+                cand = None
+                for j in np.argsort(hi - lo):            # rarest trigram first
+                    part = np.unique(ents[lo[j]:hi[j]])
+                    cand = part if cand is None else cand[np.isin(cand, part, assume_unique=True)]
+                    if len(cand) == 0:
+                        break
+                pool = cand.tolist() if cand is not None else []
+            else:
+                pool = range(len(names))                 # too short for a trigram: the plain scan
+            for e in pool:
+                if needle in names[e]:
                     if e not in found:
                         found.append(e)
                     hits += 1
@@ -320,10 +453,10 @@ class GpuIndexClient:
         return self.store.entity_names[e]
 
     def graph_chunks(self, seeds: List[int], top_k: int, hops: int = 2) -> List[str]:
-        pad = seeds + [-1] * (N.THR_GRAPH_MAX_SEEDS - len(seeds))
-        qs = torch.tensor([pad], dtype=torch.int32, device=self.index.device)
-        S, I, cnt = self.index.graph_search(qs, min(N.THR_TOPK_MAX, top_k), hops)
-        return [self.store.child_ids[int(g) - self.store.doc_base] for g in I[0, : int(cnt[0])].tolist()]
+        qs = self._upload(seeds + [-1] * (N.THR_GRAPH_MAX_SEEDS - len(seeds)), torch.int32, self.index.device)
+        S, I, _ = self.index.graph_search(qs, min(N.THR_TOPK_MAX, top_k), hops)
+        _, ids = self._download(S, I)
+        return [self.store.child_ids[int(g) - self.store.doc_base] for g in ids]
 
     # -------------------------------------------------------------- rerank
     def maxsim_scores(self, query: str, child_ids: List[str]) -> List[float]:

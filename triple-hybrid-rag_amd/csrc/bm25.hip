@@ -7,7 +7,8 @@
 // the oracle's (oracle/thr_oracle.py bm25_scores): OR semantics, float64,
 // contributions added in query-term order, every operation one IEEE rounding.
 //
-// Work decomposition: a query whose lists hold more than BM_SPLIT_MIN postings is cut
+// Work decomposition: a query whose lists hold more postings than one slice (24576 when the
+// batch fills the chip, down to 8192 when it does not) is cut
 // into DOC-RANGE slices of ~equal posting counts (the slice edges are docs of its longest
 // list), one work item per slice; short queries are one item.  A persistent grid of
 // workgroups pulls items from a device-side counter, so a stop-word query of millions of
@@ -110,7 +111,7 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
 // ---------------------------------------------------------------------------------------------
 // Work decomposition (one launch each, no host round trip):
 //   bm25_plan_kernel   per query: the valid term ids in query order, the total posting count,
-//                      the number of doc-range slices S_q (1 below BM_SPLIT_MIN postings, else
+//                      the number of doc-range slices S_q (1 up to one slice's postings, else
 //                      ~total / target, <= BM_MAX_SLICES; the target doubles until all items
 //                      fit the item list), the item list (query, slice);
 //   bm25_edges_kernel  per (item, term): the first posting of the slice in the term's list
@@ -121,19 +122,21 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
 //   bm25_merge_kernel  per query with S_q > 1: the best k of its slices' lists.
 constexpr int BM_MAX_SLICES = 128;
 constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = n_queries + this
-constexpr int BM_SPLIT_MIN = 24576;    // postings: shorter queries are one work item (<= 3 passes)
-constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at (before doubling)
+constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
+constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
+                                       // call spreads its 75 K postings over nine workgroups
 constexpr int PLAN_THREADS = 1024;
 
 __device__ __forceinline__ int bm_slices(long long tot, long long target) {
-    if (tot < BM_SPLIT_MIN) return 1;
+    if (tot <= target) return 1;   // (a query of at most one slice's postings is one work item)
     const long long s = (tot + target - 1) / target;
     return s < 1 ? 1 : s > BM_MAX_SLICES ? BM_MAX_SLICES : (int)s;
 }
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int conjunctive, int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot,
+    int nq, int mt, int cap, int conjunctive, int n_slots, int32_t* __restrict__ ctl,
+    int64_t* __restrict__ q_tot,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
     __shared__ int red[PLAN_THREADS];
@@ -158,7 +161,20 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         q_long[q] = lng;
         q_tot[q] = tot;
     }
-    long long target = BM_TARGET0;
+    // slice size: what gives every workgroup slot of the grid an item, between one pass and three
+    __shared__ long long red64[PLAN_THREADS];
+    {
+        long long t = 0;
+        for (int q = q0; q < q1; ++q) t += q_tot[q];
+        red64[threadIdx.x] = t;
+        __syncthreads();
+        for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red64[threadIdx.x] += red64[threadIdx.x + o];
+            __syncthreads();
+        }
+    }
+    long long target = red64[0] / (n_slots > 0 ? n_slots : 1);
+    target = target < BM_TARGET_MIN ? BM_TARGET_MIN : target > BM_TARGET0 ? BM_TARGET0 : target;
     int total = 0, mine = 0;
     for (;;) {
         mine = 0;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
         const int S = q_S[q], L = q_long[q];
         const int tl = q_terms[(int64_t)q * mt + L];
         const int64_t lo_l = rowptr[tl], len_l = rowptr[tl + 1] - lo_l;
-        const int64_t p = len_l * s / S;   // (S > 1 only with >= BM_SPLIT_MIN postings: len_l > S)
+        const int64_t p = len_l * s / S;   // (S > 1 only with > BM_TARGET_MIN postings: len_l >= 256 > S)
         if (slot == L) {
             pos = (int)p;
         } else {
@@ -885,9 +901,20 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
+    static int small = -1, per_cu = -1;
+    if (small < 0) {
+        const char* ev = getenv("THR_BM25_SHAPE");
+        small = (ev && ev[0] == 's') ? 1 : 0;
+        ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
+        per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
+    }
+    const bool big = !small;
+    // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
+    int grid = bm_num_cus() * (per_cu ? per_cu : (big ? 2 : 4));
+    if (grid > L.cap) grid = L.cap;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, ctl, q_tot, q_nt, q_S, q_item0, q_long, q_terms,
-                       items);
+                       n_queries, max_terms, L.cap, conjunctive, grid, ctl, q_tot, q_nt, q_S, q_item0, q_long,
+                       q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
                        rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, ipos);
@@ -898,20 +925,6 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
     // final sort) overlaps four ways, which wins when every list is short (2048 queries over lists
     // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
-    static int small = -1;
-    if (small < 0) {
-        const char* ev = getenv("THR_BM25_SHAPE");
-        small = (ev && ev[0] == 's') ? 1 : 0;
-    }
-    const bool big = !small;
-    // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
-    static int per_cu = -1;
-    if (per_cu < 0) {
-        const char* ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
-        per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
-    }
-    int grid = bm_num_cus() * (per_cu ? per_cu : (big ? 2 : 4));
-    if (grid > L.cap) grid = L.cap;
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr, avgdl, k1, b,   \

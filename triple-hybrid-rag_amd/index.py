@@ -62,6 +62,7 @@ class GpuIndex:
         self._ws: Optional[torch.Tensor] = None
         self._ws_rescue: Optional[torch.Tensor] = None
         self._ws_lex: Optional[torch.Tensor] = None
+        self._ws_graph: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------ builders
     def _t(self, a, dtype):
@@ -280,10 +281,14 @@ class GpuIndex:
         G = self.graph
         # three tiers on the device (small / full on-chip capacities, then a capacity-free walk
         # in global memory): no flag to read back, nothing to raise in the middle of a batch
+        seeds = self._t(query_seeds, torch.int32)
+        need = N.graph_workspace_bytes(seeds.shape[0], G["ent_rowptr"].shape[0] - 1)
+        if self._ws_graph is None or self._ws_graph.numel() < need:   # kept: no allocation per search
+            self._ws_graph = torch.empty(need, dtype=torch.uint8, device=self.device)
         S, I, cnt, _ = N.graph_topk(G["ent_rowptr"], G["ent_col"], G["men_rowptr"],
-                                    G["men_chunk"], G["men_conf"],
-                                    self._t(query_seeds, torch.int32), hops, k, self.doc_base,
-                                    self.n_docs, transposed=self._graph_transposed())
+                                    G["men_chunk"], G["men_conf"], seeds, hops, k, self.doc_base,
+                                    self.n_docs, transposed=self._graph_transposed(),
+                                    workspace=self._ws_graph)
         return S, I, cnt
 
     def maxsim(self, qtok: torch.Tensor, cand_global_ids: torch.Tensor) -> torch.Tensor:
@@ -309,12 +314,7 @@ class GpuIndex:
             lex = self.bm25_search(query_terms, lexical_top_k) if want_lex else None
             gra = self.graph_search(query_seeds, graph_top_k, hops) if want_gra else None
             return lex, gra, (lambda: None)
-        if getattr(self, "_side", None) is None:
-            # a high-priority queue: its short kernels get their CUs first and are gone before
-            # the scan's one-workgroup-per-CU launch needs them (triple + rerank step 4.57 ms on
-            # one stream, 4.42 with an equal-priority side stream -- THR_SIDE_STREAM=eq --, 4.32 so)
-            eq = os.environ.get("THR_SIDE_STREAM") == "eq"
-            self._side = torch.cuda.Stream(device=self.device, priority=0 if eq else -1)
+        self.side_stream()
         main = torch.cuda.current_stream(self.device)
         self._side.wait_stream(main)            # the inputs were produced on the main stream
         for t in (query_terms, query_seeds):
@@ -331,6 +331,15 @@ class GpuIndex:
         def join():
             torch.cuda.current_stream(self.device).wait_stream(self._side)
         return lex, gra, join
+
+    def side_stream(self) -> "torch.cuda.Stream":
+        if getattr(self, "_side", None) is None:
+            # a high-priority queue: its short kernels get their CUs first and are gone before
+            # the scan's one-workgroup-per-CU launch needs them (triple + rerank step 4.57 ms on
+            # one stream, 4.42 with an equal-priority side stream -- THR_SIDE_STREAM=eq --, 4.32 so)
+            eq = os.environ.get("THR_SIDE_STREAM") == "eq"
+            self._side = torch.cuda.Stream(device=self.device, priority=0 if eq else -1)
+        return self._side
 
     def retrieve_batch(self, queries: torch.Tensor, query_terms: Optional[torch.Tensor] = None,
                        query_seeds: Optional[torch.Tensor] = None, top_k: int = 10,

@@ -167,12 +167,18 @@ class RAG2Retriever:
                         modality=row.get("modality", "text"))
                 setattr(cand, rank_attr, rank)
 
+        # the channels are CALLED in the reference's order; their rows are absorbed in that order
+        # too, but only after the semantic call: a backend that defers its read-back
+        # (GpuIndexClient, ``_defer``) then has the lexical kernels running beside the dense ones
+        lex_rows = []
         if plan.keywords:
-            absorb(await self._lexical_search(keywords=plan.keywords, collection=collection,
-                                              limit=plan.lexical_top_k), "lexical_rank")
-        absorb(await self._semantic_search(query_text=plan.semantic_query_text,
-                                           collection=collection, limit=plan.semantic_top_k),
-               "semantic_rank")
+            lex_rows = await self._lexical_search(keywords=plan.keywords, collection=collection,
+                                                  limit=plan.lexical_top_k)
+        sem_rows = await self._semantic_search(query_text=plan.semantic_query_text,
+                                               collection=collection, limit=plan.semantic_top_k)
+        if plan.keywords:
+            absorb(lex_rows, "lexical_rank")
+        absorb(sem_rows, "semantic_rank")
         if self.graph_enabled and plan.requires_graph and plan.cypher_query:
             absorb(await self._graph_search(cypher=plan.cypher_query, keywords=plan.keywords,
                                             collection=collection, limit=plan.graph_top_k),
@@ -183,10 +189,12 @@ class RAG2Retriever:
     async def _lexical_search(self, keywords: List[str], collection: Optional[str],
                               limit: int) -> List[Dict[str, Any]]:
         """reference :273-292 -- one RPC, keywords joined by a space."""
-        reply = self.supabase.rpc("rag2_lexical_search", {
-            "p_org_id": self.org_id, "p_query": " ".join(keywords), "p_limit": limit,
-            "p_collection": collection}).execute()
-        return reply.data or []
+        params = {"p_org_id": self.org_id, "p_query": " ".join(keywords), "p_limit": limit,
+                  "p_collection": collection}
+        if getattr(self.supabase, "defers_readback", False):
+            params["_defer"] = True     # (not a reference parameter: only sent to a backend that asks)
+        data = self.supabase.rpc("rag2_lexical_search", params).execute().data
+        return data if data is not None else []
 
     async def _semantic_search(self, query_text: str, collection: Optional[str],
                                limit: int) -> List[Dict[str, Any]]:
