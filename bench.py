@@ -45,7 +45,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 CONFIGS = ("dense", "dense_bm25", "triple", "triple_rerank")
 BASELINE_CONFIG = {"dense": "configs[1]", "dense_bm25": "configs[2]", "triple": "configs[3]",
                    "triple_rerank": "configs[4]"}
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r2_scan_f16qs_counters.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r3_scan_f16qs_counters.json")
 
 
 def parse():
@@ -64,9 +64,14 @@ def parse():
     ap.add_argument("--token-docs", type=int, default=0,
                     help="docs that get a late-interaction token matrix (default: all; 32 KiB each)")
     ap.add_argument("--doc-shards", type=int, default=0,
-                    help="N > 1: split the corpus into this many document shards (default N: the "
-                         "pure document-sharded layout); the N / doc-shards groups are replicas "
-                         "that serve different query batches (distributed.layout_2d)")
+                    help="N > 1: split the corpus into this many document shards; the N / doc-shards "
+                         "groups are replicas that serve different query batches "
+                         "(distributed.layout_2d).  Default 0 = auto: as many shards as keep "
+                         ">= --min-shard-docs rows on a shard (the scan must dominate the per-batch "
+                         "fixed work of a shard: threshold, shortlist, rescoring, exchange), so the 1M-doc "
+                         "headline corpus is 2 shards x N/2 replicas and the 10M-doc configs are N shards; "
+                         "--doc-shards N forces the pure document-sharded layout")
+    ap.add_argument("--min-shard-docs", type=int, default=500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=2048)
     ap.add_argument("--probe-reps", type=int, default=5)
@@ -127,7 +132,12 @@ def main():
     need_tok = "triple_rerank" in run_cfgs
 
     # ---- inputs (deterministic, identical for every world size) ----
-    doc_shards = args.doc_shards or world
+    doc_shards = args.doc_shards
+    if not doc_shards:   # auto: the largest divisor of the world that leaves every shard enough rows
+        doc_shards = max(d_ for d_ in range(1, world + 1)
+                         if world % d_ == 0 and (d_ == 1 or args.docs // d_ >= args.min_shard_docs))
+        if world > 1 and doc_shards == 1 and args.docs >= 2:
+            doc_shards = min(d_ for d_ in range(2, world + 1) if world % d_ == 0)   # keep the exchange in the path
     shard, replica, _ = layout_2d(rank, world, doc_shards)
     n_replicas = world // doc_shards
     group = None
@@ -534,15 +544,18 @@ def main():
             "metric": "queries/sec (fused top-10)", "value": round(qps, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None,
+            # same corpus at every N; with replicas the per-GPU work is fixed from doc_shards GPUs on
+            "scaling": "weak" if n_replicas > 1 else "strong", "vs_baseline": None,
             "dtype": ("f32" if primary == "f32" else "f16") + " MFMA shortlist scan (f32 accumulate) + "
                      "f64 rescoring of the f32 rows",
             "data": "synthetic",
             "config": {"workload": f"{names[head_cfg]} (BASELINE.json {BASELINE_CONFIG[head_cfg]})",
                        "pipeline": head_cfg, "docs": args.docs, "dim": args.dim, "queries_per_step": nq,
                        "semantic_top_k": 100, "fused_top_k": args.top_k, "shortlist": primary,
-                       "parallelism": (f"doc-shard x{doc_shards}" + (f" x {n_replicas} replicas"
-                                       if n_replicas > 1 else "")) if world > 1 else "single GPU",
+                       "parallelism": (f"doc-shard x{doc_shards}" + (f" x {n_replicas} replicas (each serves its own "
+                                       f"{nq}-query batch per step)" if n_replicas > 1 else "") +
+                                       ("" if args.doc_shards else f"; auto layout: >= {args.min_shard_docs} rows per shard"))
+                       if world > 1 else "single GPU",
                        "collective_backend": backend, "world_size_seen": dist.get_world_size() if world > 1 else 1,
                        "rescued_queries": rescued, "input_gen_s": round(gen_s, 1),
                        "step": "thr_embed_postproc of the 4096-d query batch (resident in HBM) -> dense top-100"

@@ -1,0 +1,19 @@
+#!/bin/bash
+# The measurements a round's profiles/ are made of (one GPU, ~10 min):  scripts/collect_profiles.sh OUTDIR
+#   default bench line + rocprofv3 kernel stats of the same command; dense-only run whose scan
+#   launches all have the bench shape; shard proxies (125 K and 500 K rows); dim 1024; PMC passes
+#   over the default scan folded into the JSON bench.py quotes as roofline.traffic.
+set -e
+D=${1:-gpurun_out/collect}
+mkdir -p $D
+export TMPDIR=/tmp
+python3 bench.py > $D/bench_default.json.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_default -o bench -- python3 bench.py --no-cpu-baseline > $D/bench_default_profiled.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_dense -o dense -- python3 bench.py --config dense --no-extras --no-cpu-baseline > $D/bench_dense_only.json.log 2>&1
+python3 bench.py --docs 125000 --config dense --no-extras --no-cpu-baseline > $D/bench_shard125k.json.log 2>&1
+python3 bench.py --docs 500000 --config dense --no-extras --no-cpu-baseline > $D/bench_shard500k.json.log 2>&1
+python3 bench.py --dim 1024 --config dense --no-extras --no-cpu-baseline > $D/bench_dim1024.json.log 2>&1
+python3 bench.py --lexical-mix no-stopwords --no-cpu-baseline > $D/bench_no_stopwords.json.log 2>&1
+bash scripts/pmc_passes.sh $D/pmc_scan 2048 > $D/pmc_scan.log 2>&1
+python3 scripts/pmc_counters.py $D/pmc_scan dense_scan_f16qs $D/scan_f16qs_counters.json "768, 1" > $D/pmc_fold.log 2>&1
+ls $D

@@ -1371,7 +1371,10 @@ def test_bench_multi_rank_control_flow():
         assert len(lines) == 1
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
-        assert rec["config"]["parallelism"] == label and rec["config"]["rescued_queries"] == 0
+        assert rec["config"]["parallelism"].startswith(label) and rec["config"]["rescued_queries"] == 0
+        assert rec["scaling"] == ("weak" if "replicas" in label else "strong")
+        # where a rank's share of the step goes (scan / exchange / the rest)
+        assert set(rec["config"]["per_rank_ms"]) >= {"step_ms", "scan_ms", "exchange_ms", "fixed_ms"}
         assert rec["config"]["collective_backend"] == "gloo" and rec["config"]["world_size_seen"] == 2
         assert rec["config"]["pipeline"] == (cfg[1] if cfg else "dense")
         port += 1

@@ -135,7 +135,7 @@ __device__ __forceinline__ int bm_slices(long long tot, long long target) {
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int conjunctive, int n_slots, int32_t* __restrict__ ctl,
+    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max, int32_t* __restrict__ ctl,
     int64_t* __restrict__ q_tot,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         }
     }
     long long target = red64[0] / (n_slots > 0 ? n_slots : 1);
-    target = target < BM_TARGET_MIN ? BM_TARGET_MIN : target > BM_TARGET0 ? BM_TARGET0 : target;
+    target = target < BM_TARGET_MIN ? BM_TARGET_MIN : target > target_max ? target_max : target;
     int total = 0, mine = 0;
     for (;;) {
         mine = 0;
@@ -901,20 +901,22 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
-    static int small = -1, per_cu = -1;
+    static int small = -1, per_cu = -1, target_max = BM_TARGET0;
     if (small < 0) {
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : 0;
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
         per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
+        ev = getenv("THR_BM25_TARGET");      // postings per slice when the batch fills the grid
+        if (ev && atoi(ev) >= BM_TARGET_MIN) target_max = atoi(ev);
     }
     const bool big = !small;
     // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
     int grid = bm_num_cus() * (per_cu ? per_cu : (big ? 2 : 4));
     if (grid > L.cap) grid = L.cap;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, ctl, q_tot, q_nt, q_S, q_item0, q_long,
-                       q_terms, items);
+                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, ctl, q_tot, q_nt, q_S, q_item0,
+                       q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
                        rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, ipos);
