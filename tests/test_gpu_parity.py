@@ -345,6 +345,17 @@ def test_bm25_pruning_and_filters_stay_exact(T):
     for prune in (True, False):
         S, I, cnt = idx.bm25_search(qd, 50, prune=prune)
         assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"bm25 prune={prune}")
+    # the per-term / per-block bounds alone (no per-posting impacts): the mask path with a threshold
+    L = idx.lex
+    S, I, cnt = T._native.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"], L["avgdl"],
+                                    qd, 50, bounds=L["bounds"][:2])
+    assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], "bm25 term/block bounds only")
+    # every quantised impact bounds its posting's contribution / idf from above, within 2 steps
+    imp = L["bounds"][2].cpu().numpy().astype(np.float64)
+    tf_ = csr.post_tf.astype(np.float64)
+    nrm = 1.2 * ((1.0 - 0.75) + 0.75 * (csr.doclen[csr.post_doc].astype(np.float64) / avgdl))
+    true_imp = tf_ * 2.2 / (tf_ + nrm)
+    assert np.all(imp * (2.2 / 255.0) >= true_imp) and np.all(imp * (2.2 / 255.0) <= true_imp + 2.01 * 2.2 / 255.0)
     Sa, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50,
                          conjunctive=True)
     S, I, cnt = idx.bm25_search(qd, 50, conjunctive=True)

@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -60,9 +60,9 @@ _SIGNATURES = {
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_bm25_block_count": (_sz, [_i64]),
-    "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp]),
+    "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp, _vp]),
     "thr_bm25_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64,
+    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64,
                              _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32,
@@ -366,8 +366,8 @@ def dense_scan_stamps_f16(docs16, n_docs: int, queries_n: int, workspace: torch.
 # --------------------------------------------------------------------- a3
 def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float = 1.2,
                 b: float = 0.75):
-    """Index set-up -> (term_ub f64 [V], block_ub f64 [ceil(nnz/128)]): the upper bounds
-    thr_bm25_topk prunes with."""
+    """Index set-up -> (term_ub f64 [V], block_ub f64 [ceil(nnz/128)], post_imp u8 [nnz]): the
+    upper bounds thr_bm25_topk prunes with (per term, per 128 postings, per posting)."""
     pr = _dev(rowptr, torch.int64, "rowptr", 1)
     pdoc = _dev(post_doc, torch.int32, "post_doc", 1)
     ptf = _dev(post_tf, torch.int32, "post_tf", 1)
@@ -377,10 +377,11 @@ def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float 
     tub = torch.zeros(v, dtype=torch.float64, device=rowptr.device)
     bub = torch.zeros(max(int(load().thr_bm25_block_count(nnz)), 1), dtype=torch.float64,
                       device=rowptr.device)
+    imp = torch.zeros(max(nnz, 1), dtype=torch.uint8, device=rowptr.device)
     if nnz:
         _check(load().thr_bm25_bounds(pr, pdoc, ptf, pdl, pidf, avgdl, k1, b, v, nnz, tub.data_ptr(),
-                                      bub.data_ptr(), _stream()), "thr_bm25_bounds")
-    return tub, bub
+                                      bub.data_ptr(), imp.data_ptr(), _stream()), "thr_bm25_bounds")
+    return tub, bub, imp
 
 
 def bm25_workspace_bytes(n_queries: int, max_terms: int, k: int) -> int:
@@ -405,11 +406,15 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
     nq, mt = query_terms.shape
     if mt > THR_BM25_MAX_TERMS or k > THR_TOPK_MAX:
         raise NativeError("bm25: too many terms per query or k too large")
-    ptu = pbu = None
+    ptu = pbu = pim = None
     if bounds is not None:
         ptu, pbu = _dev(bounds[0], torch.float64, "term_ub", 1), _dev(bounds[1], torch.float64, "block_ub", 1)
         if bounds[0].shape[0] != idf.shape[0]:
             raise NativeError("bm25: term_ub length != vocabulary size")
+        if len(bounds) > 2 and bounds[2] is not None:
+            pim = _dev(bounds[2], torch.uint8, "post_imp", 1)
+            if bounds[2].shape[0] < post_doc.shape[0]:
+                raise NativeError("bm25: post_imp shorter than the posting array")
     pdc = pqc = None
     if query_coll is not None:
         if doc_coll is None:
@@ -422,7 +427,7 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=rowptr.device)
     pw = _dev(workspace, workspace.dtype, "workspace")
-    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, avgdl, k1, b, doclen.shape[0],
+    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, pim, avgdl, k1, b, doclen.shape[0],
                                 idf.shape[0], id_base, pqt, nq, mt, k, 1 if conjunctive else 0, pdc,
                                 pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), pw,
                                 workspace.numel() * workspace.element_size(), _stream()),

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void bm25_bounds_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
     const double* __restrict__ idf, double avgdl, double k1, double b, int64_t n_vocab, int64_t nnz,
-    unsigned long long* __restrict__ term_key, unsigned long long* __restrict__ block_key) {
+    unsigned long long* __restrict__ term_key, unsigned long long* __restrict__ block_key,
+    uint8_t* __restrict__ post_imp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nnz) return;
     int64_t lo = 0, hi = n_vocab;  // last term with rowptr[t] <= i
@@ -94,7 +95,17 @@ __global__ __launch_bounds__(256) void bm25_bounds_kernel(
         const int64_t mid = (lo + hi) >> 1;
         if (rowptr[mid] <= i) lo = mid; else hi = mid;
     }
-    const double c = bm25_contrib(idf[lo], (double)post_tf[i], (double)doclen[post_doc[i]], avgdl, k1, b);
+    const double tfv = (double)post_tf[i], dlv = (double)doclen[post_doc[i]];
+    const double c = bm25_contrib(idf[lo], tfv, dlv, avgdl, k1, b);
+    if (post_imp) {
+        // the posting's IMPACT tf (k1+1) / (tf + nrm) -- its contribution is idf * impact, and the
+        // impact does not depend on the query -- rounded UP to 8 bits of (k1 + 1) / 255 (one more
+        // step than the ceiling, so no rounding of this arithmetic can leave it below the impact)
+        const double nrm = __dmul_rn(k1, __dadd_rn(__dsub_rn(1.0, b), __dmul_rn(b, __ddiv_rn(dlv, avgdl))));
+        const double imp = __ddiv_rn(__dmul_rn(tfv, __dadd_rn(k1, 1.0)), __dadd_rn(tfv, nrm));
+        const int qv = (int)ceil(imp * (255.0 / (k1 + 1.0))) + 1;
+        post_imp[i] = (uint8_t)(qv > 255 ? 255 : qv < 0 ? 0 : qv);
+    }
     const unsigned long long key = dkey(c);
     atomicMax(&term_key[lo], key);
     atomicMax(&block_key[i / BM_BLOCK], key);
@@ -271,8 +282,8 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
     const double* __restrict__ idf, const double* __restrict__ term_ub,
-    const double* __restrict__ block_ub, double avgdl, double k1, double b, int64_t id_base,
-    int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
+    const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp, double avgdl, double k1,
+    double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
     const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
@@ -284,6 +295,9 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     __shared__ int t_staged[THR_BM25_MAX_TERMS];   // postings of the term staged in this pass
     __shared__ int t_subwin[THR_BM25_MAX_TERMS];   // ... of them inside the mask window
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
+    __shared__ int t_w[8];          // accumulator path: integer weight of a term's quantised impacts
+    __shared__ double acc_scale;    // ... accumulated bound = acc_scale * (real bound), rounded up
+    __shared__ int p_acc, p_thq;    // this pass takes the accumulator path; its threshold in acc units
     __shared__ int remaining, last_compact, n_surv, cur_item;
     __shared__ int64_t d_hi, d_lo, p_last;
     __shared__ double th_glob;
@@ -296,8 +310,12 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     // mask path: BM_WINDOW mask words (which query terms hold doc d_lo + slot; 1 or 4 slots per
     // word) + up to BM_WINDOW surviving slots behind them; search path: up to BM_STAGE surviving
     // staged indices; Bloom path: the bits + a work list.  One 24 KiB buffer.
-    __shared__ uint32_t scratch[BM_WINDOW + BM_WINDOW / 2];
+    // accumulator path: ACC_WORDS words of two 16-bit doc accumulators, the survivor slots behind them
+    constexpr int ACC_WORDS = BM_WINDOW, ACC_SLOTS = 2 * ACC_WORDS;   // (a wider window was measured: no gain)
+    constexpr int SCR_WORDS = ACC_WORDS + BM_WINDOW / 2;
+    __shared__ uint32_t scratch[SCR_WORDS];
     static_assert(sizeof(uint32_t) * (BM_WINDOW + BM_WINDOW / 2) >= sizeof(uint16_t) * BM_STAGE, "survivor list must fit");
+    static_assert(ACC_SLOTS <= 65536, "16-bit slot indices");
     static_assert(BM_CAP >= THR_TOPK_MAX + BM_THREADS && BM_STAGE <= 65536, "top-k buffer / 16-bit staged indices");
     static_assert(4 * BM_WINDOW <= 65536, "16-bit slot indices");
     uint32_t* mask = scratch;
@@ -337,10 +355,29 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             th_glob = -INFINITY;
         }
         tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
+        // Accumulator path (queries of <= 8 terms, OR form, impacts given): a doc's bound is the
+        // sum over its postings of idf_t * impact_q * (k1+1)/255, accumulated in 16 bits per doc
+        // slot as integers imp_q * w_t with w_t = ceil(idf_t * (k1+1)/255 * scale), scale chosen so
+        // that the weights add up to <= 256 (255 * 256 < 2^16: a slot cannot overflow into its
+        // neighbour).  It is an upper bound of the doc's score to within 1e-15, far tighter than
+        // the sum of the per-term maxima: ~1 % of the docs of a stop-word query survive it
+        // instead of ~16 %.
+        const bool acc_ok = post_imp != nullptr && !conjunctive && nt >= 1 && nt <= 8;
         if (threadIdx.x == 0) {
             int total = 0;
             for (int t = 0; t < nt; ++t) total += tr[t].len;
             remaining = total;
+            if (acc_ok) {
+                const double c = (k1 + 1.0) / 255.0;
+                double sum = 0.0;
+                for (int t = 0; t < nt; ++t) sum += t_idf[t] * c;
+                const double scale = 248.0 / sum;
+                for (int t = 0; t < nt; ++t) {
+                    int w = (int)ceil(t_idf[t] * c * scale);
+                    t_w[t] = w < 1 ? 1 : w;
+                }
+                acc_scale = scale;
+            }
         }
         __syncthreads();
 
@@ -354,6 +391,17 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 // (without a threshold every staged doc is scored in full)
                 // (sliced items only: an unsliced query is at most three passes long)
                 const bool warm = g != 0ull || (b_cnt >= k && th_s > -INFINITY) || remaining <= BM_STAGE || S == 1;
+                // with a threshold to hold them against, the pass accumulates per-doc impact bounds
+                // (2 * BM_WINDOW 16-bit slots); without one every doc is scored anyway: the mask
+                const bool have_th = g != 0ull || (b_cnt >= k && th_s > -INFINITY);
+                p_acc = acc_ok && have_th ? 1 : 0;
+                if (p_acc) {
+                    double th = (b_cnt >= k && th_s > -INFINITY) ? th_s : -INFINITY;
+                    th = th_glob > th ? th_glob : th;
+                    // prune only what is below the threshold by more than the arithmetic's slack
+                    const double tq = floor(th * acc_scale * (1.0 - 1e-12));
+                    p_thq = tq < 0.0 ? 0 : tq > 70000.0 ? 70000 : (int)tq;
+                }
                 const int stage = warm ? BM_STAGE : BM_STAGE / 4;
                 int off = 0;
                 const int spare = stage - 32 * nt;   // every list gets at least 32 slots
@@ -388,7 +436,8 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 TermRange& r = tr[threadIdx.x];
                 const int stg = t_staged[threadIdx.x];
                 r.sub = d_hi == INT64_MAX ? stg : count_below(st_doc + r.lds_off, stg, d_hi);
-                const int64_t dw = d_lo + WIN < d_hi ? d_lo + WIN : d_hi;
+                const int64_t win = p_acc ? (int64_t)ACC_SLOTS : WIN;
+                const int64_t dw = d_lo + win < d_hi ? d_lo + win : d_hi;
                 t_subwin[threadIdx.x] = dw == INT64_MAX ? stg : count_below(st_doc + r.lds_off, stg, dw);
             }
             __syncthreads();
@@ -405,7 +454,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 }
                 // wider than the mask, but the mask's width holds a fair share of the staged
                 // postings: cut the pass to that width (the rest is staged again)
-                if (total > 0 && last - d_lo > WIN && (int64_t)totw * 8 >= total) {
+                if (total > 0 && last - d_lo > (p_acc ? (int64_t)ACC_SLOTS : WIN) && (int64_t)totw * 8 >= total) {
                     total = 0;
                     last = 0;
                     for (int t = 0; t < nt; ++t) {
@@ -438,15 +487,19 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
             const int64_t last = p_last;
             const int64_t first = d_lo;
-            const bool masked = total > 0 && last - first <= WIN;
-            uint16_t* surv = masked ? reinterpret_cast<uint16_t*>(scratch + BM_WINDOW) : reinterpret_cast<uint16_t*>(scratch);
+            const bool use_acc = p_acc != 0;
+            const bool masked = total > 0 && last - first <= (use_acc ? (int64_t)ACC_SLOTS : WIN);
+            const uint32_t thq = (uint32_t)p_thq;
+            uint16_t* surv = reinterpret_cast<uint16_t*>(masked ? scratch + (use_acc ? ACC_WORDS : BM_WINDOW) : scratch);
             auto slot_mask = [&](int slot) -> uint32_t {
                 const uint32_t v = mask[slot >> ms];
                 return ms ? (v >> ((slot & 3) << 3)) & 0xFFu : v;
             };
 
             // ---- phase 2: the survivors, densely ----
-            auto phase2 = [&](bool from_mask, int ns) {
+            // survivors are staged indices of owner postings (mode 0), doc slots of the mask (1) or doc
+            // slots of the accumulators (2: which terms hold the doc is not known, every list is searched)
+            auto phase2 = [&](int mode, int ns) {
                 for (int base = 0; base < ns; base += BM_THREADS) {
                     const int j = base + threadIdx.x;
                     bool keep = j < ns;
@@ -455,7 +508,10 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     if (keep) {
                         int t = 0, at;
                         uint32_t has = 0xFFFFFFFFu;   // terms that may hold the doc
-                        if (from_mask) {   // survivor = doc slot: owner = lowest term bit, position searched
+                        if (mode == 2) {
+                            d = (int32_t)(first + surv[j]);
+                            at = 0;
+                        } else if (mode == 1) {   // survivor = doc slot: owner = lowest term bit, position searched
                             d = (int32_t)(first + surv[j]);
                             has = slot_mask(surv[j]);
                             t = __ffs((int)has) - 1;
@@ -472,14 +528,14 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                         for (int e = 0; e < 8; ++e) {
                             wf[e] = -1;
                             if (e >= t && e < nt && ((has >> e) & 1u))
-                                wf[e] = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                                wf[e] = (mode != 2 && e == t) ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
                         }
                         auto where_far = [&](int e) -> int64_t {   // e >= 8
                             if (!((has >> e) & 1u)) return -1;
                             const int f = e == t ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
                             return f >= 0 ? tr[e].lo + tr[e].cur + f : -1;
                         };
-                        if (have_theta && block_ub) {
+                        if (have_theta && block_ub && mode != 2) {   // (the impact bound is the tighter one)
                             double ub2 = 0.0;
 #pragma unroll
                             for (int e = 0; e < 8; ++e)
@@ -512,7 +568,32 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             const bool middle = !masked && have_theta && (last - first) < 32 * (int64_t)total;
             if (masked || middle) {
                 const int w = masked ? (int)(last - first) : 1;
-                if (masked) {
+                if (masked && use_acc) {
+                    const int words = (w + 1) >> 1;   // two 16-bit accumulators per word
+                    for (int i = threadIdx.x; i < words; i += BM_THREADS) mask[i] = 0u;
+                    __syncthreads();
+                    constexpr int FD = 4;   // impact loads in flight per thread and round
+                    for (int i0 = threadIdx.x; i0 < total; i0 += FD * BM_THREADS) {
+                        int slot[FD];
+                        uint32_t val[FD];
+#pragma unroll
+                        for (int u = 0; u < FD; ++u) {
+                            const int i = i0 + u * BM_THREADS;
+                            slot[u] = -1;
+                            if (i < total) {
+                                int t = 0;
+                                while (i >= t_prefix[t + 1]) ++t;
+                                const int off = i - t_prefix[t];
+                                slot[u] = (int)(st_doc[tr[t].lds_off + off] - first);
+                                val[u] = (uint32_t)post_imp[tr[t].lo + tr[t].cur + off] * (uint32_t)t_w[t];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < FD; ++u)
+                            if (slot[u] >= 0) atomicAdd(&mask[slot[u] >> 1], val[u] << ((slot[u] & 1) << 4));
+                    }
+                    __syncthreads();
+                } else if (masked) {
                     const int words = (w + spw - 1) >> ms;
                     for (int i = threadIdx.x; i < words; i += BM_THREADS) mask[i] = 0u;
                     __syncthreads();
@@ -527,7 +608,18 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 // masked: the candidate slots, BM_WINDOW slots (= the survivor list's capacity) at a
                 // time; else one round over the staged postings
                 for (int c0 = 0; c0 < w; c0 += BM_WINDOW) {
-                    if (masked) {
+                    if (masked && use_acc) {
+                        const int cend = c0 + BM_WINDOW < w ? c0 + BM_WINDOW : w;
+                        for (int wd = (c0 >> 1) + (int)threadIdx.x; wd < ((cend + 1) >> 1); wd += BM_THREADS) {
+                            const uint32_t v = mask[wd];
+                            if (!v) continue;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
+                                if (a != 0u && a >= thq) surv[atomicAdd(&n_surv, 1)] = (uint16_t)((wd << 1) + u);
+                            }
+                        }
+                    } else if (masked) {
                         const int cend = c0 + BM_WINDOW < w ? c0 + BM_WINDOW : w;
                         for (int wd = (c0 >> ms) + (int)threadIdx.x; wd < ((cend + spw - 1) >> ms); wd += BM_THREADS) {
                             const uint32_t v = mask[wd];
@@ -571,7 +663,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     }
                     __syncthreads();
                     const int ns = n_surv;
-                    phase2(masked, ns);
+                    phase2(masked ? (use_acc ? 2 : 1) : 0, ns);
                     __syncthreads();
                     if (threadIdx.x == 0) n_surv = 0;
                     __syncthreads();
@@ -585,7 +677,6 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 // of the NEXT sweep step are requested before the current one is worked on.
                 // bits per list: the largest power of two (<= 32768) that fits the buffer nt times next
                 // to a work list that could take every posting of the pass (16 bits each)
-                constexpr int SCR_WORDS = BM_WINDOW + BM_WINDOW / 2;
                 int bwords = 1024;
                 while (bwords >= 128 && nt * bwords + (total + 1) / 2 > SCR_WORDS) bwords >>= 1;
                 const bool bloom = bwords >= 128;
@@ -841,7 +932,7 @@ extern "C" size_t thr_bm25_block_count(int64_t nnz) { return nnz > 0 ? (size_t)(
 extern "C" int thr_bm25_bounds(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
                                const float* doclen, const double* idf, double avgdl, double k1,
                                double b, int64_t n_vocab, int64_t nnz, double* term_ub,
-                               double* block_ub, thr_stream_t stream) {
+                               double* block_ub, uint8_t* post_imp, thr_stream_t stream) {
     clear_status();
     THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !doclen || !idf || !term_ub || !block_ub,
                   THR_ERR_INVALID);
@@ -853,7 +944,7 @@ extern "C" int thr_bm25_bounds(const int64_t* rowptr, const int32_t* post_doc, c
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(bm25_bounds_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, rowptr,
                        post_doc, post_tf, doclen, idf, avgdl, k1, b, n_vocab, nnz,
-                       (unsigned long long*)term_ub, (unsigned long long*)block_ub);
+                       (unsigned long long*)term_ub, (unsigned long long*)block_ub, post_imp);
     hipLaunchKernelGGL(bm25_bounds_decode, dim3((unsigned)((n_vocab + 255) / 256)), dim3(256), 0, st,
                        (unsigned long long*)term_ub, n_vocab);
     hipLaunchKernelGGL(bm25_bounds_decode, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st,
@@ -868,7 +959,7 @@ extern "C" size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k) 
 
 extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
                              const float* doclen, const double* idf, const double* term_ub,
-                             const double* block_ub, double avgdl, double k1, double b,
+                             const double* block_ub, const uint8_t* post_imp, double avgdl, double k1, double b,
                              int64_t n_docs, int64_t n_vocab, int64_t id_base,
                              const int32_t* query_terms, int n_queries, int max_terms, int k,
                              int conjunctive, const int32_t* doc_coll, const int32_t* query_coll,
@@ -901,8 +992,10 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
-    static int small = -1, per_cu = -1, target_max = BM_TARGET0;
+    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1;
     if (small < 0) {
+        const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
+        use_imp = !(ei && ei[0] == '0');
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : 0;
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
@@ -929,7 +1022,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
-                       post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr, avgdl, k1, b,   \
+                       post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
+                       (term_ub && use_imp) ? post_imp : nullptr, avgdl, k1, b,                     \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
                        q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,       \
                        out_ids, out_counts)
