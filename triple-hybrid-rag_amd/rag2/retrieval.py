@@ -62,6 +62,10 @@ _CHANNELS = (("lexical", "lexical_rank", 0.7), ("semantic", "semantic_rank", 0.8
              ("graph", "graph_rank", 1.0))
 
 
+def _rrf_key(c: RetrievalCandidate) -> float:
+    return c.rrf_score
+
+
 def _effective_score(c: RetrievalCandidate) -> float:
     # a rerank score of exactly 0.0 is falsy and falls through to the RRF score (:476, :489)
     return c.rerank_score or c.rrf_score
@@ -157,14 +161,14 @@ class RAG2Retriever:
         merged: Dict[str, RetrievalCandidate] = {}
 
         def absorb(rows, rank_attr):
+            # (the per-row work of a call: ~150 rows; positional construction, one dict probe)
+            get, make = merged.get, RetrievalCandidate
             for rank, row in enumerate(rows, 1):
                 key = row["child_id"]
-                cand = merged.get(key)
+                cand = get(key)
                 if cand is None:
-                    cand = merged[key] = RetrievalCandidate(
-                        child_id=key, parent_id=row["parent_id"], document_id=row["document_id"],
-                        text=row["text"], page=row.get("page", 1),
-                        modality=row.get("modality", "text"))
+                    cand = merged[key] = make(key, row["parent_id"], row["document_id"], row["text"],
+                                              row.get("page", 1), row.get("modality", "text"))
                 setattr(cand, rank_attr, rank)
 
         # the channels are CALLED in the reference's order; their rows are absorbed in that order
@@ -232,14 +236,17 @@ class RAG2Retriever:
                   k: int = RRF_K) -> List[RetrievalCandidate]:
         """reference :358-376 -- float64, add order lexical -> semantic -> graph, missing
         weights default to 0.7/0.8/1.0, stable descending sort."""
+        w_l, w_s, w_g = (weights.get(name, default) for name, _attr, default in _CHANNELS)
         for cand in candidates:
-            total = 0.0
-            for name, attr, default in _CHANNELS:
-                rank = getattr(cand, attr)
-                if rank:
-                    total += weights.get(name, default) / (k + rank)
+            total = 0.0          # (same adds in the same order as the loop over the channels)
+            if cand.lexical_rank:
+                total += w_l / (k + cand.lexical_rank)
+            if cand.semantic_rank:
+                total += w_s / (k + cand.semantic_rank)
+            if cand.graph_rank:
+                total += w_g / (k + cand.graph_rank)
             cand.rrf_score = total
-        return sorted(candidates, key=lambda c: c.rrf_score, reverse=True)
+        return sorted(candidates, key=_rrf_key, reverse=True)
 
     async def _expand_to_parents(self, candidates: List[RetrievalCandidate]
                                  ) -> List[RetrievalCandidate]:
