@@ -351,7 +351,7 @@ def test_bm25_pruning_and_filters_stay_exact(T):
                                     qd, 50, bounds=L["bounds"][:2])
     assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], "bm25 term/block bounds only")
     # every quantised impact bounds its posting's contribution / idf from above, within 2 steps
-    imp = L["bounds"][2].cpu().numpy().astype(np.float64)
+    imp = L["bounds"][2].cpu().numpy().astype(np.float64)[:len(csr.post_tf)]   # (4 bytes of padding behind)
     tf_ = csr.post_tf.astype(np.float64)
     nrm = 1.2 * ((1.0 - 0.75) + 0.75 * (csr.doclen[csr.post_doc].astype(np.float64) / avgdl))
     true_imp = tf_ * 2.2 / (tf_ + nrm)

@@ -377,7 +377,7 @@ def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float 
     tub = torch.zeros(v, dtype=torch.float64, device=rowptr.device)
     bub = torch.zeros(max(int(load().thr_bm25_block_count(nnz)), 1), dtype=torch.float64,
                       device=rowptr.device)
-    imp = torch.zeros(max(nnz, 1), dtype=torch.uint8, device=rowptr.device)
+    imp = torch.zeros(nnz + 4, dtype=torch.uint8, device=rowptr.device)   # (+4: read as aligned 32-bit words)
     if nnz:
         _check(load().thr_bm25_bounds(pr, pdoc, ptf, pdl, pidf, avgdl, k1, b, v, nnz, tub.data_ptr(),
                                       bub.data_ptr(), imp.data_ptr(), _stream()), "thr_bm25_bounds")

@@ -29,7 +29,9 @@
 // bounds come from binary searches in LDS and only the survivors touch memory.
 // Term frequencies and doc lengths are read only for the postings that need them.
 // Algorithmic bytes per query: sum_t df_t * (4 doc + 4 tf + 4 doclen) + T * 16.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "thr_common.hpp"
 
 namespace thr {
@@ -210,13 +212,19 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         red[threadIdx.x] += v;
         __syncthreads();
     }
-    int base = red[threadIdx.x] - mine;
+    // Item order: slice 0 of EVERY query first (item q), then the other slices query by query
+    // (item q_item0[q] + s, s >= 1).  The slices of a query that are started together all begin
+    // without a threshold and score every doc of their first pass in full; with this order a
+    // query's first slice has published its threshold (theta_glob) long before most of its other
+    // slices are taken, and those start with the pruning already in force.
+    int rest = (red[threadIdx.x] - mine) - q0;   // slices s >= 1 of the queries before this thread's
     for (int q = q0; q < q1; ++q) {
         const int S = bm_slices(q_tot[q], target);
         q_S[q] = S;
-        q_item0[q] = base;
-        for (int s = 0; s < S; ++s) items[base + s] = make_int2(q, s);
-        base += S;
+        q_item0[q] = nq + rest - 1;
+        items[q] = make_int2(q, 0);
+        for (int s = 1; s < S; ++s) items[nq + rest + s - 1] = make_int2(q, s);
+        rest += S - 1;
     }
     if (threadIdx.x == 0) ctl[0] = total;
 }
@@ -233,21 +241,28 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
     const int2 it = items[item];
     const int q = it.x, s = it.y;
     if (slot >= q_nt[q]) return;
-    int pos = 0;
-    if (s > 0) {
-        const int S = q_S[q], L = q_long[q];
+    const int term = q_terms[(int64_t)q * mt + slot];
+    const int64_t lo = rowptr[term];
+    const int full = (int)(rowptr[term + 1] - lo);
+    int start = 0, end = full;
+    const int S = q_S[q];
+    if (S > 1) {
+        const int L = q_long[q];
         const int tl = q_terms[(int64_t)q * mt + L];
         const int64_t lo_l = rowptr[tl], len_l = rowptr[tl + 1] - lo_l;
-        const int64_t p = len_l * s / S;   // (S > 1 only with > BM_TARGET_MIN postings: len_l >= 256 > S)
-        if (slot == L) {
-            pos = (int)p;
-        } else {
-            const int term = q_terms[(int64_t)q * mt + slot];
-            const int64_t lo = rowptr[term];
-            pos = count_below(post_doc + lo, (int)(rowptr[term + 1] - lo), (int64_t)post_doc[lo_l + p]);
-        }
+        // edge e of S: the (len * e / S)-th doc of the longest list (S > 1 only with > BM_TARGET_MIN
+        // postings: len_l >= 256 > S, the edges are distinct)
+        auto edge = [&](int e) -> int {
+            if (e == 0) return 0;
+            if (e == S) return full;
+            const int64_t p = len_l * e / S;
+            return slot == L ? (int)p : count_below(post_doc + lo, full, (int64_t)post_doc[lo_l + p]);
+        };
+        start = edge(s);
+        end = edge(s + 1);
     }
-    ipos[(int64_t)item * mt + slot] = pos;
+    ipos[((int64_t)item * mt + slot) * 2] = start;
+    ipos[((int64_t)item * mt + slot) * 2 + 1] = end;
 }
 
 // An item's postings are consumed in DOC-RANGE passes.  A pass stages, from every term's list,
@@ -277,6 +292,25 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
 // list" with one LDS read; singletons are scored (or dropped on term_ub) at once, the others
 // are searched from a dense work list.  In between, with a threshold: owners and bounds by
 // binary search in LDS.
+// BM_STAMPS (diagnostic build, _build.build_variant("stamps", ["BM_STAMPS"]); scripts/bm25_stamps.py):
+// thread 0 of every workgroup adds the cycles between consecutive phase marks into buckets,
+// written behind the workspace; thr_bm25_topk then waits for the launch and prints the shares.
+#ifdef BM_STAMPS
+constexpr int BM_NSTAMP = 20;   // 0-13 phases (cycles), 14-19 counters
+#define BM_STAMP(i)                                                       \
+    do {                                                                  \
+        if (threadIdx.x == 0) {                                           \
+            const unsigned long long now_ = __builtin_readcyclecounter(); \
+            stamp_acc[i] += now_ - stamp_last;                            \
+            stamp_last = now_;                                            \
+        }                                                                 \
+    } while (0)
+#define BM_COUNT(i, v) do { if (threadIdx.x == 0) stamp_acc[i] += (unsigned long long)(v); } while (0)
+#else
+#define BM_STAMP(i)
+#define BM_COUNT(i, v)
+#endif
+
 template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP>
 __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
@@ -289,7 +323,15 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
     const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
     double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
-    double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt) {
+    double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt
+#ifdef BM_STAMPS
+    , unsigned long long* __restrict__ stamps
+#endif
+    ) {
+#ifdef BM_STAMPS
+    unsigned long long stamp_acc[BM_NSTAMP] = {0};
+    unsigned long long stamp_last = __builtin_readcyclecounter(), stamp_items = 0;
+#endif
     __shared__ TermRange tr[THR_BM25_MAX_TERMS];   // .sub = postings of this pass, .lds_off = where staged
     __shared__ double t_idf[THR_BM25_MAX_TERMS], t_ub[THR_BM25_MAX_TERMS];
     __shared__ int t_staged[THR_BM25_MAX_TERMS];   // postings of the term staged in this pass
@@ -312,10 +354,12 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     // staged indices; Bloom path: the bits + a work list.  One 24 KiB buffer.
     // accumulator path: ACC_WORDS words of two 16-bit doc accumulators, the survivor slots behind them
     constexpr int ACC_WORDS = BM_WINDOW, ACC_SLOTS = 2 * ACC_WORDS;   // (a wider window was measured: no gain)
-    constexpr int SCR_WORDS = ACC_WORDS + BM_WINDOW / 2;
+    // survivor slots of a scan: SURV_CAP 16-bit entries behind the masks / accumulators (with a
+    // threshold a window has ~100 survivors; a scan that finds more is redone SURV_CAP slots at a time)
+    constexpr int SURV_CAP = BM_WINDOW;
+    constexpr int SCR_WORDS = ACC_WORDS + SURV_CAP / 2;
     __shared__ uint32_t scratch[SCR_WORDS];
-    static_assert(sizeof(uint32_t) * (BM_WINDOW + BM_WINDOW / 2) >= sizeof(uint16_t) * BM_STAGE, "survivor list must fit");
-    static_assert(ACC_SLOTS <= 65536, "16-bit slot indices");
+    static_assert(sizeof(uint32_t) * SCR_WORDS >= sizeof(uint16_t) * BM_STAGE, "survivor list of the search path must fit");
     static_assert(BM_CAP >= THR_TOPK_MAX + BM_THREADS && BM_STAGE <= 65536, "top-k buffer / 16-bit staged indices");
     static_assert(4 * BM_WINDOW <= 65536, "16-bit slot indices");
     uint32_t* mask = scratch;
@@ -342,17 +386,20 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             const int term = q_terms[(int64_t)q * max_terms + slot];
             const int64_t lo = rowptr[term];
             const int full = (int)(rowptr[term + 1] - lo);
-            const int start = ipos[(int64_t)item * max_terms + slot];
-            const int end = sl == S - 1 ? full : ipos[(int64_t)(item + 1) * max_terms + slot];
+            const int start = ipos[((int64_t)item * max_terms + slot) * 2];
+            const int end = ipos[((int64_t)item * max_terms + slot) * 2 + 1];
             tr[slot].lo = lo + start;
             tr[slot].len = end - start;
             tr[slot].cur = 0;
             t_idf[slot] = idf[term];
             t_ub[slot] = term_ub ? term_ub[term] : INFINITY;
         }
+        BM_STAMP(0);
         if (threadIdx.x == 0) {
             last_compact = 0;
-            th_glob = -INFINITY;
+            const unsigned long long g0 = S > 1 ? __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            th_glob = g0 ? dkey_inv(g0) : -INFINITY;
         }
         tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);  // includes a barrier
         // Accumulator path (queries of <= 8 terms, OR form, impacts given): a doc's bound is the
@@ -380,13 +427,15 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             }
         }
         __syncthreads();
+        BM_STAMP(1);
 
         while (remaining > 0) {
             // ---- quotas: the stage is shared out in proportion to what is left of each list ----
             if (threadIdx.x == 0) {
-                const unsigned long long g = S > 1 ? __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED,
-                                                                       __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                th_glob = g ? dkey_inv(g) : -INFINITY;
+                // (th_glob: read at the item's start and again in every staging interval -- the load
+                // of the other slices' threshold travels WITH the staging loads, it is never a round
+                // trip of its own on the pass's critical path)
+                const unsigned long long g = th_glob > -INFINITY ? 1ull : 0ull;
                 // no threshold anywhere yet and a long way to go: a short first pass gets one cheaply
                 // (without a threshold every staged doc is scored in full)
                 // (sliced items only: an unsliced query is at most three passes long)
@@ -417,6 +466,10 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 d_lo = INT64_MAX;
             }
             __syncthreads();
+            BM_STAMP(2);
+            unsigned long long gth = 0ull;
+            if (threadIdx.x == 0 && S > 1)
+                gth = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int t = 0; t < nt; ++t) {
                 const int32_t* src = post_doc + tr[t].lo + tr[t].cur;
                 int32_t* dst = st_doc + tr[t].lds_off;
@@ -424,7 +477,9 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 // store was A/B-measured on one box: 5 % slower -- the registers it holds cost more)
                 for (int i = threadIdx.x; i < t_staged[t]; i += BM_THREADS) dst[i] = src[i];
             }
+            if (threadIdx.x == 0 && S > 1) th_glob = gth ? dkey_inv(gth) : -INFINITY;
             __syncthreads();
+            BM_STAMP(3);
             if ((int)threadIdx.x < nt) {
                 const int t = threadIdx.x;
                 if (t_staged[t] > 0 && tr[t].cur + t_staged[t] < tr[t].len)   // more postings behind the quota
@@ -478,6 +533,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 n_surv = 0;
             }
             __syncthreads();
+            BM_STAMP(4);
             const int total = t_prefix[nt];
             const double thg = th_glob;                 // the query's other slices' threshold (or -inf)
             const bool have_local = b_cnt >= k && th_s > -INFINITY;
@@ -492,7 +548,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             const bool use_acc = p_acc != 0;
             const bool masked = total > 0 && last - first <= (use_acc ? (int64_t)ACC_SLOTS : WIN);
             const uint32_t thq = (uint32_t)p_thq;
-            uint16_t* surv = reinterpret_cast<uint16_t*>(masked ? scratch + (use_acc ? ACC_WORDS : BM_WINDOW) : scratch);
+            uint16_t* surv = reinterpret_cast<uint16_t*>(masked ? scratch + ACC_WORDS : scratch);   // (ACC_WORDS == BM_WINDOW)
             auto slot_mask = [&](int slot) -> uint32_t {
                 const uint32_t v = mask[slot >> ms];
                 return ms ? (v >> ((slot & 3) << 3)) & 0xFFu : v;
@@ -526,11 +582,47 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                         // staged position of the doc in every term that holds it (first 8 terms in
                         // registers -- static indexing only --, the rest searched again when needed)
                         int wf[8];
+                        if (mode == 2 && nt <= 4) {
+                            // the (up to four) lower-bound searches advance in lockstep, branch-free: four
+                            // independent LDS reads per step instead of four chains one after the other
+                            int lo_[4], hi_[4], base_[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                lo_[e] = 0;
+                                hi_[e] = e < nt ? tr[e].sub : 0;
+                                base_[e] = e < nt ? tr[e].lds_off : 0;
+                            }
+                            int span = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) span = hi_[e] > span ? hi_[e] : span;
+#pragma unroll 1
+                            for (; span > 0; span >>= 1) {
+                                int mid[4];
+                                int32_t v[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    mid[e] = (lo_[e] + hi_[e]) >> 1;
+                                    v[e] = st_doc[base_[e] + (lo_[e] < hi_[e] ? mid[e] : 0)];
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bool live = lo_[e] < hi_[e], right = v[e] < d;
+                                    lo_[e] = live && right ? mid[e] + 1 : lo_[e];
+                                    hi_[e] = live && !right ? mid[e] : hi_[e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) wf[e] = -1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)   // lo = the lower bound: the doc is there iff it equals d
+                                if (e < nt && lo_[e] < tr[e].sub && st_doc[base_[e] + lo_[e]] == d) wf[e] = lo_[e];
+                        } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             wf[e] = -1;
                             if (e >= t && e < nt && ((has >> e) & 1u))
                                 wf[e] = (mode != 2 && e == t) ? at - tr[e].lds_off : find_doc(st_doc + tr[e].lds_off, tr[e].sub, d);
+                        }
                         }
                         auto where_far = [&](int e) -> int64_t {   // e >= 8
                             if (!((has >> e) & 1u)) return -1;
@@ -574,27 +666,36 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     const int words = (w + 1) >> 1;   // two 16-bit accumulators per word
                     for (int i = threadIdx.x; i < words; i += BM_THREADS) mask[i] = 0u;
                     __syncthreads();
-                    constexpr int FD = 4;   // impact loads in flight per thread and round
-                    for (int i0 = threadIdx.x; i0 < total; i0 += FD * BM_THREADS) {
-                        int slot[FD];
-                        uint32_t val[FD];
+                    // term by term: everything that depends on the term is uniform (scalar registers),
+                    // a posting costs one LDS read, one byte from global memory and one LDS atomic
+                    for (int t = 0; t < nt; ++t) {
+                        const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
+                        const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
+                        const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane(t_w[t]);
+                        // (staging the impacts in LDS with the ids -- bytes, or aligned words -- was measured:
+                        // what the fill gains the staging loses)
+                        const uint8_t* imp_t = post_imp + tr[t].lo + tr[t].cur;
+                        for (int i0 = threadIdx.x; i0 < sub; i0 += 4 * BM_THREADS) {
+                            int slot[4];
+                            uint32_t val[4];
 #pragma unroll
-                        for (int u = 0; u < FD; ++u) {
-                            const int i = i0 + u * BM_THREADS;
-                            slot[u] = -1;
-                            if (i < total) {
-                                int t = 0;
-                                while (i >= t_prefix[t + 1]) ++t;
-                                const int off = i - t_prefix[t];
-                                slot[u] = (int)(st_doc[tr[t].lds_off + off] - first);
-                                val[u] = (uint32_t)post_imp[tr[t].lo + tr[t].cur + off] * (uint32_t)t_w[t];
+                            for (int u = 0; u < 4; ++u) {
+                                const int i = i0 + u * BM_THREADS;
+                                slot[u] = -1;
+                                if (i < sub) {
+                                    slot[u] = (int)(st_doc[off0 + i] - first);
+                                    val[u] = (uint32_t)imp_t[i] * wt;
+                                }
                             }
-                        }
 #pragma unroll
-                        for (int u = 0; u < FD; ++u)
-                            if (slot[u] >= 0) atomicAdd(&mask[slot[u] >> 1], val[u] << ((slot[u] & 1) << 4));
+                            for (int u = 0; u < 4; ++u)
+                                if (slot[u] >= 0) atomicAdd(&mask[slot[u] >> 1], val[u] << ((slot[u] & 1) << 4));
+                        }
                     }
                     __syncthreads();
+                    BM_STAMP(12);
+                    BM_COUNT(14, 1);
+                    BM_COUNT(16, total);
                 } else if (masked) {
                     const int words = (w + spw - 1) >> ms;
                     for (int i = threadIdx.x; i < words; i += BM_THREADS) mask[i] = 0u;
@@ -606,23 +707,33 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                         atomicOr(&mask[slot >> ms], 1u << (((slot & (spw - 1)) << 3) + t));
                     }
                     __syncthreads();
+                    BM_STAMP(12);
+                    BM_COUNT(15, 1);
+                    BM_COUNT(16, total);
                 }
                 // masked: the candidate slots, BM_WINDOW slots (= the survivor list's capacity) at a
                 // time; else one round over the staged postings
-                for (int c0 = 0; c0 < w; c0 += BM_WINDOW) {
+                // the whole window at once when its survivors fit the list (BM_WINDOW slots: they do
+                // once a threshold prunes), else BM_WINDOW slots at a time
+                int c_step = masked ? w : SURV_CAP;
+                for (int c0 = 0; c0 < w;) {
+                    const int c_next = c0 + c_step < w ? c0 + c_step : w;
                     if (masked && use_acc) {
-                        const int cend = c0 + BM_WINDOW < w ? c0 + BM_WINDOW : w;
+                        const int cend = c_next;
                         for (int wd = (c0 >> 1) + (int)threadIdx.x; wd < ((cend + 1) >> 1); wd += BM_THREADS) {
                             const uint32_t v = mask[wd];
                             if (!v) continue;
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
                                 const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
-                                if (a != 0u && a >= thq) surv[atomicAdd(&n_surv, 1)] = (uint16_t)((wd << 1) + u);
+                                if (a != 0u && a >= thq) {
+                                    const int at = atomicAdd(&n_surv, 1);
+                                    if (at < SURV_CAP) surv[at] = (uint16_t)((wd << 1) + u);
+                                }
                             }
                         }
                     } else if (masked) {
-                        const int cend = c0 + BM_WINDOW < w ? c0 + BM_WINDOW : w;
+                        const int cend = c_next;
                         for (int wd = (c0 >> ms) + (int)threadIdx.x; wd < ((cend + spw - 1) >> ms); wd += BM_THREADS) {
                             const uint32_t v = mask[wd];
                             if (!v) continue;
@@ -635,7 +746,8 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                                     for (uint32_t r = m; r; r &= r - 1) ub = __dadd_rn(ub, t_ub[__ffs((int)r) - 1]);
                                     if (pruned(ub)) continue;
                                 }
-                                surv[atomicAdd(&n_surv, 1)] = (uint16_t)((wd << ms) + u);
+                                const int at = atomicAdd(&n_surv, 1);
+                                if (at < SURV_CAP) surv[at] = (uint16_t)((wd << ms) + u);
                             }
                         }
                     } else {
@@ -664,11 +776,23 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                         }
                     }
                     __syncthreads();
+                    BM_STAMP(13);
                     const int ns = n_surv;
+                    if (masked && ns > SURV_CAP) {   // (only with c_step == w) too many: again, chunk by chunk
+                        __syncthreads();
+                        if (threadIdx.x == 0) n_surv = 0;
+                        __syncthreads();
+                        c_step = SURV_CAP;
+                        continue;
+                    }
+                    BM_COUNT(17, ns);
+                    BM_COUNT(18, (ns + BM_THREADS - 1) / BM_THREADS);
                     phase2(masked ? (use_acc ? 2 : 1) : 0, ns);
                     __syncthreads();
                     if (threadIdx.x == 0) n_surv = 0;
                     __syncthreads();
+                    BM_STAMP(5);
+                    c0 = c_next;
                 }
             } else {
                 // sparse lists (or no threshold yet): every owner is scored in the same sweep that finds it.
@@ -751,7 +875,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 // bits is the doc's only posting (owner, one contribution) and is scored at once; the
                 // few with a set bit -- which a wave would otherwise wait for, lane by lane -- go to a
                 // work list (behind the bits in the same buffer) that sweep 2 walks densely.
-                static_assert(2 * (BM_WINDOW + BM_WINDOW / 2) >= BM_STAGE, "work list of a pass without the filter");
+                static_assert(2 * SCR_WORDS >= BM_STAGE, "work list of a pass without the filter");
                 uint16_t* work = reinterpret_cast<uint16_t*>(bloom ? scratch + nt * bwords : scratch);
                 // (n_surv is 0 here: it counts the work list now)
                 if (bloom) {
@@ -805,6 +929,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     push(owner, score, (int64_t)d);
                 }
             }
+            BM_STAMP(9);
             __syncthreads();
             // a fresh theta pays for the select once enough docs have entered since the last one
             if (b_cnt >= k && b_cnt - last_compact >= 64) {
@@ -820,6 +945,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 remaining -= total;
             }
             __syncthreads();
+            BM_STAMP(10);
         }
         const int n = tk.finish();
         if (S == 1) {
@@ -838,7 +964,17 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 if (n >= k) atomicMax(&theta_glob[q], (unsigned long long)dkey(b_s[k - 1]));
             }
         }
+        BM_STAMP(11);
+#ifdef BM_STAMPS
+        ++stamp_items;
+#endif
     }
+#ifdef BM_STAMPS
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < BM_NSTAMP; ++i) stamps[(int64_t)blockIdx.x * (BM_NSTAMP + 1) + i] = stamp_acc[i];
+        stamps[(int64_t)blockIdx.x * (BM_NSTAMP + 1) + BM_NSTAMP] = stamp_items;
+    }
+#endif
 }
 
 // The best k of a sliced query's per-slice lists (order: score desc, id asc -- the slices hold
@@ -864,12 +1000,13 @@ __global__ __launch_bounds__(BMM_THREADS) void bm25_merge_kernel(
     for (int base = 0; base < S * k; base += BMM_THREADS) {
         const int idx = base + threadIdx.x;
         const int sl = idx / k, j = idx - sl * k;
-        const bool ok = sl < S && j < slice_cnt[item0 + sl];
+        const int item = sl == 0 ? q : item0 + sl;   // (slice 0 is item q: bm25_plan_kernel)
+        const bool ok = sl < S && j < slice_cnt[item];
         double sc = 0.0;
         int64_t id = 0;
         if (ok) {
-            sc = slice_s[(int64_t)(item0 + sl) * k + j];
-            id = slice_id[(int64_t)(item0 + sl) * k + j];
+            sc = slice_s[(int64_t)item * k + j];
+            id = slice_id[(int64_t)item * k + j];
         }
         tk.push(ok, sc, id);
     }
@@ -884,7 +1021,7 @@ __global__ __launch_bounds__(BMM_THREADS) void bm25_merge_kernel(
 // ---- workspace of thr_bm25_topk ----
 struct BmLayout {
     size_t off_ctl, off_theta, off_tot, off_nt, off_S, off_item0, off_long, off_qterms, off_items,
-        off_ipos, off_ss, off_sid, off_scnt, total;
+        off_ipos, off_ss, off_sid, off_scnt, off_stamps, total;
     int cap;
 };
 static BmLayout bm_layout(int nq, int mt, int k) {
@@ -905,10 +1042,13 @@ static BmLayout bm_layout(int nq, int mt, int k) {
     L.off_long = take(sizeof(int32_t) * nq);
     L.off_qterms = take(sizeof(int32_t) * (size_t)nq * mt);
     L.off_items = take(sizeof(int2) * (size_t)L.cap);
-    L.off_ipos = take(sizeof(int32_t) * (size_t)(L.cap + 1) * mt);
+    L.off_ipos = take(sizeof(int32_t) * 2 * (size_t)L.cap * mt);
     L.off_ss = take(sizeof(double) * (size_t)L.cap * k);
     L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
     L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
+#ifdef BM_STAMPS
+    L.off_stamps = take(sizeof(unsigned long long) * 4096 * (BM_NSTAMP + 1));
+#endif
     L.total = off;
     return L;
 }
@@ -999,15 +1139,15 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
         use_imp = !(ei && ei[0] == '0');
         const char* ev = getenv("THR_BM25_SHAPE");
-        small = (ev && ev[0] == 's') ? 1 : 0;
+        small = (ev && ev[0] == 's') ? 1 : (ev && ev[0] == 'h') ? 2 : 0;   // s(mall) / h(uge)
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
         per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
         ev = getenv("THR_BM25_TARGET");      // postings per slice when the batch fills the grid
         if (ev && atoi(ev) >= BM_TARGET_MIN) target_max = atoi(ev);
     }
-    const bool big = !small;
+    const bool big = small == 0, huge = small == 2;
     // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
-    int grid = bm_num_cus() * (per_cu ? per_cu : (big ? 2 : 4));
+    int grid = bm_num_cus() * (per_cu ? per_cu : (huge ? 1 : big ? 2 : 4));
     if (grid > L.cap) grid = L.cap;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
                        n_queries, max_terms, L.cap, conjunctive, grid, target_max, ctl, q_tot, q_nt, q_S, q_item0,
@@ -1022,16 +1162,46 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
     // final sort) overlaps four ways, which wins when every list is short (2048 queries over lists
     // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
+#ifdef BM_STAMPS
+    unsigned long long* d_stamps = (unsigned long long*)(ws + L.off_stamps);
+    if (grid > 4096) grid = 4096;
+#define BM_STAMP_ARG , d_stamps
+#else
+#define BM_STAMP_ARG
+#endif
 #define THR_BM25_LAUNCH(T, S, W, C)                                                                \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
                        (term_ub && use_imp) ? post_imp : nullptr, avgdl, k1, b,                     \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
                        q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,       \
-                       out_ids, out_counts)
-    if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024);
+                       out_ids, out_counts BM_STAMP_ARG)
+    if (huge) THR_BM25_LAUNCH(1024, 16384, 8192, 2048);   // one 16-wave workgroup per CU, passes twice as long
+    else if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024);
     else THR_BM25_LAUNCH(256, 4096, 2048, 512);
 #undef THR_BM25_LAUNCH
+#ifdef BM_STAMPS
+    {
+        static const char* names[BM_NSTAMP] = {"item set-up", "init", "quotas", "staging", "edges/prefix", "phase 2 (+ chunk reset)",
+                                               "", "", "", "sparse path", "compact/advance", "finish",
+                                               "mask / acc fill", "slot scan / middle search", "#acc passes", "#mask passes",
+                                               "#postings masked", "#survivors", "#phase2 rounds", ""};
+        std::vector<unsigned long long> h((size_t)grid * (BM_NSTAMP + 1));
+        hipStreamSynchronize(st);
+        hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double tot[BM_NSTAMP + 1] = {0};
+        for (int g = 0; g < grid; ++g)
+            for (int i = 0; i <= BM_NSTAMP; ++i) tot[i] += (double)h[(size_t)g * (BM_NSTAMP + 1) + i];
+        double all = 0;
+        for (int i = 0; i < 14; ++i) all += tot[i];
+        fprintf(stderr, "[bm25 stamps] %d queries, %d workgroups, %.0f items, %.0f cycles per workgroup:", n_queries, grid,
+                tot[BM_NSTAMP], all / grid);
+        for (int i = 0; i < 14; ++i)
+            if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
+        for (int i = 14; i < 19; ++i) fprintf(stderr, " %s %.0f", names[i], tot[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if ((rc = launch_status())) return rc;
     hipLaunchKernelGGL(bm25_merge_kernel, dim3(n_queries), dim3(BMM_THREADS), 0, st, q_S, q_item0,
                        slice_s, slice_id, slice_cnt, k, out_scores, out_ids, out_counts);
