@@ -373,6 +373,35 @@ def test_bm25_pruning_and_filters_stay_exact(T):
     assert len(If[5]) == 0 and all(coll[i] == 7 for i in If[0])
 
 
+def test_bm25_term_counts_k_and_tiny_corpora(T):
+    """Every phase-1 form of the BM25 pass against the oracle: queries of 1 / 2 / 5 / 8 terms
+    (accumulated impact bounds), 9 / 12 / 32 terms (32-bit doc masks), k = 1 / 128, stop words in
+    every position, a 300-doc corpus (one workgroup, one pass) and a sliced one; with and without
+    the bounds, OR and AND."""
+    from triple_hybrid_rag_amd import synth
+    for n in (300, 90000):
+        csr, idf, avgdl, v = lexical_fixture(T, n)
+        idx = T.GpuIndex().set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+        top = np.argsort(-csr.df_local)[:40].astype(np.int32)     # the longest lists
+        rng = np.random.default_rng(n)
+        for nt in (1, 2, 5, 8, 9, 12, 32):
+            qt = np.full((24, nt), -1, dtype=np.int32)
+            for i in range(24):
+                m = 1 + i % nt                                     # 1 .. nt terms, the rest padding
+                pick = np.concatenate([top[rng.permutation(min(len(top), 8 + nt))[:(m + 1) // 2]],
+                                       rng.integers(0, v, size=m)])[:m]
+                qt[i, rng.permutation(nt)[:m]] = pick              # padding anywhere in the row
+            for k in (1, 50, 128):
+                Se, Ie = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, k)
+                for prune in (True, False):
+                    S, I, cnt = idx.bm25_search(dev(qt), k, prune=prune)
+                    assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"bm25 n={n} nt={nt} k={k} prune={prune}")
+            Sa, Ia = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 20,
+                                 conjunctive=True)
+            S, I, cnt = idx.bm25_search(dev(qt), 20, conjunctive=True)
+            assert_topk_equal(S, I, cnt, Sa, Ia, [len(s) for s in Sa], f"bm25 AND n={n} nt={nt}")
+
+
 @pytest.mark.parametrize("shortlist", ["f32", "f16", "f16-inline"])
 def test_dense_collection_filter_before_topk(T, shortlist):
     """p_collection is a WHERE clause (rag2_schema.sql:404-408): the limit best rows OF THE
