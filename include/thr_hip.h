@@ -204,8 +204,8 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * contribution is idf * impact, the impact does not depend on the query -- rounded UP to 8 bits
  * of (k1+1)/255.  Given to thr_bm25_topk, OR queries of <= 8 terms hold each candidate doc
  * against the SUM of its own postings' quantised impacts (accumulated in 16 bits per doc slot on
- * chip) instead of the sum of the per-term maxima: ~1 % of the docs of a stop-word query survive
- * that bound, ~16 % the coarse one.  Results are the same bits either way. */
+ * chip) instead of the sum of the per-term maxima: ~2.5 % of the postings of a stop-word query lead
+ * to a survivor of that bound, ~16 % with the coarse one.  Results are the same bits either way. */
 /* term ids outside [0, n_vocab) have no postings: the OR form ignores them, with conjunctive != 0 a
  * non-negative one makes the query unsatisfiable (empty result, as the SQL AND would give).  term_ub / block_ub (or NULL: score
  * every posting): a doc whose bound cannot beat the running k-th best score is dropped before its
