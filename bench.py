@@ -104,7 +104,8 @@ def main():
     import torch.distributed as dist
     import triple_hybrid_rag_amd as T
     from triple_hybrid_rag_amd import synth
-    from triple_hybrid_rag_amd.distributed import ShardedIndex, layout_2d, replica_groups, shard_range
+    from triple_hybrid_rag_amd.distributed import (ShardedIndex, auto_doc_shards, layout_2d, replica_groups,
+                                                  shard_range)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,11 +134,8 @@ def main():
 
     # ---- inputs (deterministic, identical for every world size) ----
     doc_shards = args.doc_shards
-    if not doc_shards:   # auto: the largest divisor of the world that leaves every shard enough rows
-        doc_shards = max(d_ for d_ in range(1, world + 1)
-                         if world % d_ == 0 and (d_ == 1 or args.docs // d_ >= args.min_shard_docs))
-        if world > 1 and doc_shards == 1 and args.docs >= 2:
-            doc_shards = min(d_ for d_ in range(2, world + 1) if world % d_ == 0)   # keep the exchange in the path
+    if not doc_shards:   # auto: shard only as far as the scan still dominates a shard's step
+        doc_shards = auto_doc_shards(world, args.docs, args.min_shard_docs)
     shard, replica, _ = layout_2d(rank, world, doc_shards)
     n_replicas = world // doc_shards
     group = None

@@ -386,3 +386,73 @@ def test_tool_layer_matches_reference(golden, settings_guard, monkeypatch):
     monkeypatch.setattr(crm, "get_supabase_client", lambda: (_ for _ in ()).throw(RuntimeError("db down")))
     err = crm.search_knowledge_base("q", "faq")
     assert err == {"error": "Database error: db down", "query": "q", "category": "faq"}
+
+
+def test_entity_lookup_index_equals_the_plain_scan():
+    """GpuIndexClient.find_entities (graph_search.py:161-170: name ILIKE %kw%, first 5 keywords,
+    limit // len(keywords) entities each, ascending entity order) through the trigram index must
+    return what the O(E) scan over the names returns -- accents, case, keywords shorter than a
+    trigram, keywords nobody matches, duplicates across keywords."""
+    from triple_hybrid_rag_amd import _native as N
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    names = [f"entity{e}" for e in range(3000)] + ["Ação Ltda", "açúcar união", "Acme Corp", "acme holdings",
+                                                   "xy", "x", "ACME", "São Paulo S.A.", ""]
+    store = CorpusStore.synthetic(8)
+    store.entity_names = names
+
+    class Client(GpuIndexClient):
+        def __init__(self):
+            self.store = store
+
+    client = Client()
+
+    def scan(keywords, limit):
+        per, found = max(1, limit // len(keywords)), []
+        for kw in keywords[:5]:
+            needle, hits = kw.lower(), 0
+            for e, name in enumerate(names):
+                if needle in name.lower():
+                    if e not in found:
+                        found.append(e)
+                    hits += 1
+                    if hits == per:
+                        break
+        return found[: N.THR_GRAPH_MAX_SEEDS]
+
+    for kws in (["entity12"], ["entity4", "acme"], ["AÇÃO", "união", "zzz"], ["xy", "x", "ent"], ["São", "s.a."],
+                ["tity299", "e", "ac", "corp", "hold", "ignored"], ["entity"], ["ACME", "acme", "Acme"]):
+        for limit in (20, 50, 3, 1):
+            assert client.find_entities(kws, limit) == scan(kws, limit), (kws, limit)
+    assert client.find_entities([], 20) == []
+
+
+def test_lazy_rows_and_the_layout_rule():
+    from triple_hybrid_rag_amd.backend import LazyRows
+    from triple_hybrid_rag_amd.distributed import auto_doc_shards, layout_2d
+    calls = []
+    rows = LazyRows(lambda: calls.append(1) or [{"child_id": "a"}, {"child_id": "b"}])
+    assert calls == []                       # nothing is read back before the rows are looked at
+    assert [r["child_id"] for r in rows] == ["a", "b"] and len(rows) == 2 and rows and calls == [1]
+    assert rows[1]["child_id"] == "b" and rows == [{"child_id": "a"}, {"child_id": "b"}] and calls == [1]
+    broken = LazyRows(lambda: 1 / 0)         # a failing deferred part is an empty channel
+    assert list(broken) == [] and not broken
+    # one GPU: no split; the 1M-doc headline corpus: 2 shards x N/2 replicas; 10M docs: N shards
+    assert [auto_doc_shards(w, 1_000_000) for w in (1, 2, 4, 8)] == [1, 2, 2, 2]
+    assert [auto_doc_shards(w, 10_000_000) for w in (1, 2, 4, 8)] == [1, 2, 4, 8]
+    assert [auto_doc_shards(w, 40_000) for w in (2, 8)] == [2, 2]      # the exchange stays in the path
+    assert auto_doc_shards(6, 2_000_000) == 3 and auto_doc_shards(8, 2_000_000, 250_000) == 8
+    assert layout_2d(5, 8, 2) == (1, 2, [4, 5])
+
+
+def test_synthetic_global_lexical_statistics():
+    """synth.lexical_global_stats (what ONE shard needs for the global idf / avgdl) equals the
+    statistics of the rows themselves, and a shard's rows are the unsharded corpus' rows."""
+    import numpy as np
+    from triple_hybrid_rag_amd import synth
+    n = 150_000
+    df, sum_dl = synth.lexical_global_stats(n)
+    doc, term, tf = synth.lexical_rows(0, n, n)
+    assert np.array_equal(df, np.bincount(term, minlength=synth.vocab_size(n))) and sum_dl == float(tf.sum())
+    d2, t2, f2 = synth.lexical_rows(70_000, 50_000, n)
+    sel = (doc >= 70_000) & (doc < 120_000)
+    assert np.array_equal(d2 + 70_000, doc[sel]) and np.array_equal(t2, term[sel]) and np.array_equal(f2, tf[sel])

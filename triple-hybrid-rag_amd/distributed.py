@@ -42,6 +42,20 @@ def layout_2d(rank: int, world: int, doc_shards: int):
     return shard, replica, list(range(replica * doc_shards, (replica + 1) * doc_shards))
 
 
+def auto_doc_shards(world: int, n_docs: int, min_shard_docs: int = 500_000) -> int:
+    """How many document shards ``world`` GPUs should cut an ``n_docs`` corpus into: the largest
+    divisor of the world that leaves every shard >= ``min_shard_docs`` rows (a shard's step is the
+    scan, which shrinks with the shard, plus per-batch work that does not; below ~500 K rows the
+    fixed part dominates and more replicas beat more shards) -- but at least 2 when there is more
+    than one GPU, so that the exchange stays in the path.  The other world / shards groups are
+    replicas that serve their own query batches (layout_2d)."""
+    best = max(d for d in range(1, world + 1)
+               if world % d == 0 and (d == 1 or n_docs // d >= min_shard_docs))
+    if world > 1 and best == 1 and n_docs >= 2:
+        best = min(d for d in range(2, world + 1) if world % d == 0)
+    return best
+
+
 def replica_groups(world: int, doc_shards: int):
     """One process group per replica (every rank must create all of them, in this order)."""
     return [dist.new_group(list(range(r * doc_shards, (r + 1) * doc_shards)))
