@@ -28,9 +28,9 @@ log = logging.getLogger(__name__)
 RRF_K = 60
 
 
-@dataclass
+@dataclass(slots=True)
 class RetrievalCandidate:
-    """reference retrieval.py:26-47"""
+    """reference retrieval.py:26-47 (slots: ~150 of these are built per call)"""
     child_id: str
     parent_id: str
     document_id: str
