@@ -337,6 +337,10 @@ class GpuIndexClient:
         """defer=True (``_defer`` in the RPC's params; RAG2Retriever sets it): the kernels are
         enqueued on the index's side stream and the rows are read back when first looked at --
         the retriever issues its semantic RPC in between, and the two channels overlap."""
+        pending = getattr(self, "_pending_lex", None)
+        if pending is not None:     # a deferred call still owns the index's lexical workspace:
+            pending._ready()        # read it back before the kernels of this one are enqueued
+            self._pending_lex = None
         terms: List[int] = []
         unknown = False
         for tok in tokenize(query):
@@ -375,7 +379,8 @@ class GpuIndexClient:
             with torch.cuda.stream(side):   # the copy is ordered after the kernels on their stream
                 scores, ids = self._download(S, I)
             return self._rows(ids, scores, len(ids), "rank", limit)
-        return LazyRows(fetch)
+        self._pending_lex = LazyRows(fetch)
+        return self._pending_lex
 
     # -------------------------------------------------------------- tables
     def table(self, name: str) -> _TableQuery:
