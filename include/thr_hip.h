@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 6
+#define THR_ABI_VERSION 7
 
 typedef void *thr_stream_t;
 
@@ -222,11 +222,29 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * atomic max and are merged at the end -- a stop-word query is the job of many workgroups, not
  * of one.  ``workspace`` >= thr_bm25_workspace_bytes(n_queries, max_terms, k): item list, slice
  * edges, per-slice lists. */
+/* Dense terms (ABI 7).  A stop word's posting list is most of the corpus; walking it posting by
+ * posting is the slowest way to learn that nearly all of its docs cannot make the top-k.  The
+ * caller picks the terms held by a large share of the docs (the host layer: df >= n_docs / 8,
+ * tf <= 65535, at most 512 of them), lists them in ``terms`` and gets, per term, one ROW of
+ * thr_bm25_dense_stride(n_docs) entries: dense_imp[row][d] = post_imp of doc d's posting (0: the
+ * doc does not hold the term), dense_tf[row][d] = its term frequency.  dense_slot [V] maps a
+ * term to its row (-1: not dense).  Given to thr_bm25_topk, OR queries of <= 8 terms that hold a
+ * dense term walk the shard in doc windows: the dense terms' impacts come as coalesced loads of
+ * the rows, only the other terms' postings are staged; the survivors of the impact bound are
+ * scored from dense_tf / post_tf with the same arithmetic.  Results are the same bits. */
+int64_t thr_bm25_dense_stride(int64_t n_docs);
+int thr_bm25_dense_rows(const int64_t *rowptr, const int32_t *post_doc, const int32_t *post_tf,
+                        const uint8_t *post_imp, const int32_t *terms /* [n_terms] */, int n_terms,
+                        int64_t n_docs, int64_t max_df /* longest of those lists */,
+                        uint8_t *dense_imp /* [n_terms, stride] */,
+                        uint16_t *dense_tf /* [n_terms, stride] */, thr_stream_t stream);
 size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k);
 int thr_bm25_topk(const int64_t *rowptr /* [V+1] */, const int32_t *post_doc,
                   const int32_t *post_tf, const float *doclen /* [n_docs] */,
                   const double *idf /* [V] */, const double *term_ub, const double *block_ub,
                   const uint8_t *post_imp /* [nnz] or NULL */,
+                  const int32_t *dense_slot /* [V] or NULL */, const uint8_t *dense_imp,
+                  const uint16_t *dense_tf, int64_t dense_stride,
                   double avgdl, double k1, double b, int64_t n_docs, int64_t n_vocab,
                   int64_t id_base, const int32_t *query_terms, int n_queries, int max_terms, int k,
                   int conjunctive, const int32_t *doc_coll, const int32_t *query_coll,

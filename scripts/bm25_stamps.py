@@ -29,7 +29,8 @@ def main():
     dfq = csr.df_local.copy()
     dfq[dfq > 0.01 * n] = 0
     for name, qt in (("bench mix (no stop words)", synth.lexical_queries(nq, dfq, 4)),
-                     ("df-proportional, 256 queries", synth.lexical_queries(256, csr.df_local, 4))):
+                     ("df-proportional, 256 queries", synth.lexical_queries(256, csr.df_local, 4)),
+                     ("df-proportional, full batch", synth.lexical_queries(nq, csr.df_local, 4))):
         qd = torch.from_numpy(qt).cuda()
         print(name, file=sys.stderr, flush=True)
         for _ in range(2):

@@ -373,6 +373,70 @@ def test_bm25_pruning_and_filters_stay_exact(T):
     assert len(If[5]) == 0 and all(coll[i] == 7 for i in If[0])
 
 
+def test_bm25_dense_term_rows_equal_the_posting_walk(T):
+    """Terms held by a large share of the docs get per-doc rows of impacts / term frequencies
+    (thr_bm25_dense_rows) and their queries take the doc-window kernel: same bits as the posting
+    walk and as the oracle -- at the default share, at a low one (most query terms dense), on an
+    odd-sized shard with a doc base, with the collection filter, for k = 1 / 50 / 128, and with a
+    list that is sparse overall but packed into one stretch of doc ids."""
+    from triple_hybrid_rag_amd import synth
+    n = 70001
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    # a list of 6000 postings packed into docs [30000, 36000): sparse by its share (8.6 %), locally dense
+    rp, pd, pt = csr.rowptr.copy(), csr.post_doc.copy(), csr.post_tf.copy()
+    packed = int(np.argsort(-csr.df_local)[60])
+    lo, hi = int(rp[packed]), int(rp[packed + 1])
+    docs = np.arange(30000, 36000, dtype=np.int32)
+    pd = np.concatenate([pd[:lo], docs, pd[hi:]])
+    pt = np.concatenate([pt[:lo], 1 + (docs % 3), pt[hi:]]).astype(np.int32)
+    rp[packed + 1:] += len(docs) - (hi - lo)
+    df = (rp[1:] - rp[:-1]).astype(np.int64)
+    top = np.argsort(-df)[:12].astype(np.int32)
+    qt = synth.lexical_queries(64, df, 4)
+    qt[0] = top[:4]
+    qt[1] = [top[0], packed, top[5], -1]
+    qt[2] = [packed, -1, -1, -1]
+    qt[3] = [top[1], top[1], v + 3, -1]          # repeated dense term, an id outside the vocabulary
+    qt[4] = [int(np.argsort(-df)[5000]), top[2], -1, top[3]]
+    qt[5] = -1
+    coll = (np.arange(n) % 9).astype(np.int32)
+    qc = np.full(64, -1, dtype=np.int32)
+    qc[::4] = 3
+    for share in (0.125, 0.01):
+        idx = T.GpuIndex(doc_base=1000).set_lexical(rp, pd, pt, csr.doclen, idf, avgdl, dense_share=share)
+        idx.set_collections(coll)
+        dense = idx.lex["dense"]
+        assert dense is not None and dense[1].shape[0] == min(512, int((df >= share * n).sum()))
+        assert (int(dense[0][packed]) >= 0) == (share < 0.08)
+        # the rows are the postings, scattered: impact and tf of a few docs of the longest list
+        t0 = int(top[0])
+        row = int(dense[0][t0])
+        a, b = int(rp[t0]), int(rp[t0 + 1])
+        got_tf = dense[2][row].cpu().numpy().astype(np.int64)[:n]
+        exp_tf = np.zeros(n, dtype=np.int64)
+        exp_tf[pd[a:b]] = pt[a:b]
+        assert np.array_equal(got_tf, exp_tf)
+        imp = idx.lex["bounds"][2].cpu().numpy()
+        exp_imp = np.zeros(n, dtype=np.uint8)
+        exp_imp[pd[a:b]] = imp[a:b]
+        assert np.array_equal(dense[1][row].cpu().numpy()[:n], exp_imp)
+        assert not dense[1][row][n:].any()          # zero padding behind the shard's docs
+        for k in (1, 50, 128):
+            Se, Ie = O.bm25_topk(rp, pd, pt, csr.doclen, idf, avgdl, qt, n, k, doc_id_base=1000)
+            S, I, cnt = idx.bm25_search(dev(qt), k)
+            assert_topk_equal(S, I, cnt, Se, Ie, [len(s) for s in Se], f"bm25 dense rows share={share} k={k}")
+            S2, I2, cnt2 = idx.bm25_search(dev(qt), k, dense_rows=False)
+            assert torch.equal(S, S2) and torch.equal(I, I2) and torch.equal(cnt, cnt2)
+        Sf, If = O.bm25_topk(rp, pd, pt, csr.doclen, idf, avgdl, qt, n, 50, doc_id_base=1000,
+                             doc_coll=coll, query_coll=qc)
+        S, I, cnt = idx.bm25_search(dev(qt), 50, collections=dev(qc))
+        assert_topk_equal(S, I, cnt, Sf, If, [len(s) for s in Sf], f"bm25 dense rows + collection share={share}")
+        # one query alone (unsliced below 24576 work units, sliced above), and a 1-doc-wide last slice
+        S1, I1, cnt1 = idx.bm25_search(dev(qt[:1]), 50)
+        Se, Ie = O.bm25_topk(rp, pd, pt, csr.doclen, idf, avgdl, qt[:1], n, 50, doc_id_base=1000)
+        assert_topk_equal(S1, I1, cnt1, Se, Ie, [len(s) for s in Se], "bm25 dense rows, one query")
+
+
 def test_bm25_term_counts_k_and_tiny_corpora(T):
     """Every phase-1 form of the BM25 pass against the oracle: queries of 1 / 2 / 5 / 8 terms
     (accumulated impact bounds), 9 / 12 / 32 terms (32-bit doc masks), k = 1 / 128, stop words in

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in thr_hip.h but not exported"
     assert sorted(T._native.EXPORTED_SYMBOLS) == names
-    assert lib.thr_abi_version() == T._native.ABI_VERSION == 6
+    assert lib.thr_abi_version() == T._native.ABI_VERSION == 7
     assert lib.thr_error_string(-3) == b"workspace too small"
 
 
@@ -32,8 +32,11 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.thr_dense_topk(None, None, None, 10, 768, 0, None, 1, 10, 128, None, None, None, None,
                               None, None, None, 0, None) == -1
     # bm25: a vocabulary size is part of the call (term ids >= V are ignored, not dereferenced)
-    assert lib.thr_bm25_topk(None, None, None, None, None, None, None, None, 1.0, 1.2, 0.75, 10, 5, 0, None,
-                             1, 4, 10, 0, None, None, None, None, None, None, 0, None) == -1
+    assert lib.thr_bm25_topk(None, None, None, None, None, None, None, None, None, None, None, 0, 1.0, 1.2, 0.75,
+                             10, 5, 0, None, 1, 4, 10, 0, None, None, None, None, None, None, 0, None) == -1
+    # dense-term rows: one window of zero padding behind the shard's docs, 16-byte aligned
+    assert lib.thr_bm25_dense_stride(1000) == 1008 + 16384 and lib.thr_bm25_dense_stride(0) == 0
+    assert lib.thr_bm25_dense_rows(None, None, None, None, None, 1, 10, 5, None, None, None) == -1
     # the work decomposition's item list, slice edges and per-slice lists: grows with nq, terms, k
     assert lib.thr_bm25_workspace_bytes(2048, 4, 50) > (2048 + 8192) * 50 * 16
     assert lib.thr_bm25_workspace_bytes(2048, 32, 50) > lib.thr_bm25_workspace_bytes(2048, 4, 50)

@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 
@@ -62,7 +62,9 @@ _SIGNATURES = {
     "thr_bm25_block_count": (_sz, [_i64]),
     "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp, _vp]),
     "thr_bm25_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64,
+    "thr_bm25_dense_stride": (_i64, [_i64]),
+    "thr_bm25_dense_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "thr_bm25_topk": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _i64, _i64, _i64,
                              _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_graph_workspace_bytes": (_sz, [_i32, _i64]),
     "thr_graph_topk": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32,
@@ -384,6 +386,37 @@ def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float 
     return tub, bub, imp
 
 
+def bm25_dense_terms(rowptr, post_doc, post_tf, post_imp, n_docs: int, min_share: float = 0.125,
+                     max_terms: int = 512):
+    """Index set-up -> (dense_slot i32 [V], dense_imp u8 [T, stride], dense_tf u16 [T, stride],
+    stride) for the terms held by at least ``min_share`` of the docs (the ``max_terms`` longest
+    of them, term frequencies <= 65535), or None when there is none: per-doc rows of impacts and
+    term frequencies, so that thr_bm25_topk never walks a stop word's postings."""
+    _dev(rowptr, torch.int64, "rowptr", 1)
+    df = rowptr[1:] - rowptr[:-1]
+    cand = torch.nonzero(df.to(torch.float64) >= min_share * n_docs).flatten()
+    if cand.numel() == 0 or n_docs <= 0:
+        return None
+    keep = []
+    for t in cand[torch.argsort(df[cand], descending=True, stable=True)][:max_terms].tolist():
+        lo, hi = int(rowptr[t]), int(rowptr[t + 1])
+        if int(post_tf[lo:hi].max()) <= 65535:
+            keep.append(t)
+    if not keep:
+        return None
+    terms = torch.tensor(sorted(keep), dtype=torch.int32, device=rowptr.device)
+    stride = int(load().thr_bm25_dense_stride(n_docs))
+    dimp = torch.empty((len(keep), stride), dtype=torch.uint8, device=rowptr.device)
+    dtf = torch.empty((len(keep), stride), dtype=torch.int16, device=rowptr.device)   # (read as uint16)
+    _check(load().thr_bm25_dense_rows(_dev(rowptr, torch.int64, "rowptr", 1), _dev(post_doc, torch.int32, "post_doc", 1),
+                                      _dev(post_tf, torch.int32, "post_tf", 1), _dev(post_imp, torch.uint8, "post_imp", 1),
+                                      terms.data_ptr(), len(keep), n_docs, int(df[terms.long()].max()),
+                                      dimp.data_ptr(), dtf.data_ptr(), _stream()), "thr_bm25_dense_rows")
+    slot = torch.full((rowptr.shape[0] - 1,), -1, dtype=torch.int32, device=rowptr.device)
+    slot[terms.long()] = torch.arange(len(keep), dtype=torch.int32, device=rowptr.device)
+    return slot, dimp, dtf, stride
+
+
 def bm25_workspace_bytes(n_queries: int, max_terms: int, k: int) -> int:
     return int(load().thr_bm25_workspace_bytes(n_queries, max_terms, k))
 
@@ -391,8 +424,9 @@ def bm25_workspace_bytes(n_queries: int, max_terms: int, k: int) -> int:
 def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms, k: int,
               id_base: int = 0, k1: float = 1.2, b: float = 0.75, bounds=None,
               conjunctive: bool = False, doc_coll=None, query_coll=None,
-              workspace: Optional[torch.Tensor] = None):
-    """``workspace``: a uint8 device tensor of >= bm25_workspace_bytes(nq, max_terms, k) bytes
+              workspace: Optional[torch.Tensor] = None, dense=None):
+    """``dense``: bm25_dense_terms' tuple (needs ``bounds`` with the impacts).
+    ``workspace``: a uint8 device tensor of >= bm25_workspace_bytes(nq, max_terms, k) bytes
     (item list, slice edges and per-slice lists of the work decomposition); allocated when
     missing or too small."""
     pr = _dev(rowptr, torch.int64, "rowptr", 1)
@@ -415,6 +449,15 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
             pim = _dev(bounds[2], torch.uint8, "post_imp", 1)
             if bounds[2].shape[0] < post_doc.shape[0]:
                 raise NativeError("bm25: post_imp shorter than the posting array")
+    pds = pdi = pdt = None
+    dstride = 0
+    if dense is not None:
+        if pim is None:
+            raise NativeError("bm25: dense rows need the bounds with the impacts")
+        pds, pdi = _dev(dense[0], torch.int32, "dense_slot", 1), _dev(dense[1], torch.uint8, "dense_imp", 2)
+        pdt, dstride = _dev(dense[2], torch.int16, "dense_tf", 2), int(dense[3])
+        if dense[0].shape[0] != idf.shape[0] or dense[1].shape != dense[2].shape or dense[1].shape[1] != dstride:
+            raise NativeError("bm25: dense rows are inconsistent")
     pdc = pqc = None
     if query_coll is not None:
         if doc_coll is None:
@@ -427,7 +470,8 @@ def bm25_topk(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, query_terms,
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=rowptr.device)
     pw = _dev(workspace, workspace.dtype, "workspace")
-    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, pim, avgdl, k1, b, doclen.shape[0],
+    _check(load().thr_bm25_topk(pr, pdoc, ptf, pdl, pidf, ptu, pbu, pim, pds, pdi, pdt, dstride,
+                                avgdl, k1, b, doclen.shape[0],
                                 idf.shape[0], id_base, pqt, nq, mt, k, 1 if conjunctive else 0, pdc,
                                 pqc, S.data_ptr(), I.data_ptr(), cnt.data_ptr(), pw,
                                 workspace.numel() * workspace.element_size(), _stream()),

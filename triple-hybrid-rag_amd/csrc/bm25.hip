@@ -121,6 +121,28 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
     }
 }
 
+// DENSE TERMS (stop words: a term held by at least an eighth of the docs, chosen by the caller at
+// index set-up).  Besides its CSR postings such a term gets one byte and one 16-bit word PER DOC:
+// its quantised impact (post_imp of the doc's posting, 0 where the doc does not hold the term)
+// and its term frequency (0 likewise).  bm25_window_kernel then needs no posting of the term at
+// all: the bound of doc d is a coalesced byte load at [row + d], the exact contribution comes
+// from the frequency at [row + d] -- no staging, no LDS atomics, no position search.
+__global__ __launch_bounds__(256) void bm25_dense_rows_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
+    const int32_t* __restrict__ post_tf, const uint8_t* __restrict__ post_imp,
+    const int32_t* __restrict__ terms, int64_t stride, uint8_t* __restrict__ dense_imp,
+    uint16_t* __restrict__ dense_tf) {
+    const int row = blockIdx.y;
+    const int term = terms[row];
+    const int64_t lo = rowptr[term], hi = rowptr[term + 1];
+    for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t at = (int64_t)row * stride + post_doc[i];
+        const int32_t tf = post_tf[i];
+        dense_imp[at] = post_imp[i];
+        dense_tf[at] = (uint16_t)(tf > 65535 ? 65535 : tf);   // (the caller keeps terms with tf > 65535 out)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Work decomposition (one launch each, no host round trip):
 //   bm25_plan_kernel   per query: the valid term ids in query order, the total posting count,
@@ -134,6 +156,7 @@ __global__ void bm25_bounds_decode(unsigned long long* __restrict__ keys, int64_
 //   bm25_topk_kernel   persistent workgroups pull items from ctl[1];
 //   bm25_merge_kernel  per query with S_q > 1: the best k of its slices' lists.
 constexpr int BM_MAX_SLICES = 128;
+constexpr int BW_PAD = 16384;          // docs per window of bm25_window_kernel = zero padding of a dense row
 constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = n_queries + this
 constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
 constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
@@ -146,9 +169,15 @@ __device__ __forceinline__ int bm_slices(long long tot, long long target) {
     return s < 1 ? 1 : s > BM_MAX_SLICES ? BM_MAX_SLICES : (int)s;
 }
 
+// first doc of slice s of S of a window-kernel query (even: the 16-bit loads of the dense rows)
+__device__ __forceinline__ int64_t bm_window_edge(int64_t n_docs, int s, int S) {
+    return s >= S ? n_docs : (n_docs * s / S) & ~(int64_t)1;
+}
+
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max, int32_t* __restrict__ ctl,
+    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max,
+    const int32_t* __restrict__ dense_slot, int64_t n_docs, int32_t* __restrict__ ctl,
     int64_t* __restrict__ q_tot,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
@@ -158,8 +187,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int q1 = q0 + per < nq ? q0 + per : nq;
     for (int q = q0; q < q1; ++q) {
         int nt = 0, lng = 0;
-        long long tot = 0, best = -1;
+        long long tot = 0, best = -1, sparse = 0;
         bool dead = false;   // AND mode: a term outside the vocabulary is held by no doc
+        bool dense = false;
         for (int j = 0; j < mt; ++j) {
             const int term = query_terms[(int64_t)q * mt + j];
             if (term >= n_vocab && conjunctive) dead = true;
@@ -168,8 +198,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
             if (len > best) { best = len; lng = nt; }
             q_terms[(int64_t)q * mt + nt++] = term;
             tot += len;
+            if (dense_slot && dense_slot[term] >= 0) dense = true; else sparse += len;
         }
         if (dead) nt = 0, tot = 0;   // (nothing to score: the item writes an empty list)
+        // a query with a dense term (OR form, <= 8 terms) is the window kernel's: its work is one
+        // unit per doc of the shard plus the postings of its other terms, its slices are doc ranges
+        if (dense && !conjunctive && nt <= 8) {
+            lng = -1;
+            tot = n_docs + sparse;
+            atomicAdd(&ctl[3], 1);
+        }
         q_nt[q] = nt;
         q_long[q] = lng;
         q_tot[q] = tot;
@@ -234,7 +272,7 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
     const int32_t* __restrict__ ctl, const int32_t* __restrict__ q_nt,
     const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items, int mt,
-    int32_t* __restrict__ ipos) {
+    const int32_t* __restrict__ dense_slot, int64_t n_docs, int32_t* __restrict__ ipos) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int item = (int)(g / mt), slot = (int)(g % mt);
     if (item >= ctl[0]) return;
@@ -246,7 +284,16 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
     const int full = (int)(rowptr[term + 1] - lo);
     int start = 0, end = full;
     const int S = q_S[q];
-    if (S > 1) {
+    if (q_long[q] < 0) {
+        // window kernel: slice s is the doc range [bm_window_edge(s), bm_window_edge(s + 1));
+        // a dense term needs no postings, the others are cut by binary search
+        if (dense_slot[term] >= 0) {
+            start = end = 0;
+        } else if (S > 1) {
+            start = count_below(post_doc + lo, full, bm_window_edge(n_docs, s, S));
+            end = count_below(post_doc + lo, full, bm_window_edge(n_docs, s + 1, S));
+        }
+    } else if (S > 1) {
         const int L = q_long[q];
         const int tl = q_terms[(int64_t)q * mt + L];
         const int64_t lo_l = rowptr[tl], len_l = rowptr[tl + 1] - lo_l;
@@ -319,7 +366,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp, double avgdl, double k1,
     double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
-    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
     const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
     double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
@@ -374,6 +421,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
         if (item >= n_items) break;   // (uniform: every workgroup of the grid ends here)
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
+        if (q_long[q] < 0) continue;   // a query with a dense term: bm25_window_kernel's
         const int S = q_S[q];
         const int nt = q_nt[q];
         const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
@@ -977,6 +1025,383 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// bm25_window_kernel: the items of queries that hold a DENSE term (bm25_dense_rows_kernel).
+// An item is a doc range; a pass takes the next window of up to BW_DOCS docs.  The dense terms
+// add their quantised impacts straight from their per-doc rows into per-thread registers
+// (coalesced dword loads: 4 docs each); the other terms' postings of the window (doc ids and
+// impacts) are staged in LDS and added into 16-bit LDS accumulators as in bm25_topk_kernel's
+// accumulator path.  A doc whose total bound reaches the threshold survives; phase 2 reads its
+// term frequencies -- per-doc rows for the dense terms, the posting found by binary search among
+// the staged ids for the others -- and scores it with the oracle's arithmetic in query-term
+// order.  Same exactness argument as the accumulator path (the bound is >= acc_scale * score),
+// same top-k / threshold sharing / slice merge as bm25_topk_kernel.
+//
+// A pass is a chain of dependent round trips, not of bytes, so its steps are arranged to need
+// few of them: the next pass's quotas and threshold are computed in the tail of the current one
+// (next to the select), every thread derives the pass's end itself from the staged ids (no
+// "edges" step), and how many staged postings a pass consumed is counted off the critical path.
+template <int BW_THREADS, int BW_STAGE, int BW_DOCS, int BW_CAP>
+__global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
+    const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
+    const double* __restrict__ idf, const uint8_t* __restrict__ post_imp,
+    const int32_t* __restrict__ dense_slot, const uint8_t* __restrict__ dense_imp,
+    const uint16_t* __restrict__ dense_tf, int64_t dense_stride, double avgdl, double k1, double b,
+    int64_t n_docs, int64_t id_base, int max_terms, int k, const int32_t* __restrict__ doc_coll,
+    const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
+    const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
+    const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
+    double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
+    double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt
+#ifdef BM_STAMPS
+    , unsigned long long* __restrict__ stamps
+#endif
+    ) {
+#ifdef BM_STAMPS
+    unsigned long long stamp_acc[BM_NSTAMP] = {0};
+    unsigned long long stamp_last = __builtin_readcyclecounter(), stamp_items = 0;
+#endif
+    constexpr int ACC_WORDS = BW_DOCS / 2;            // two 16-bit doc accumulators per word
+    // the dense rows are summed and scanned BW_SCAN docs at a time (what a thread's registers hold)
+    constexpr int BW_SCAN = BW_DOCS < 8192 ? BW_DOCS : 8192;
+    constexpr int QPT = BW_SCAN / 4 / BW_THREADS;     // dwords of a dense row per thread and scan (4 docs each)
+    constexpr int SURV_CAP = 4096 < BW_SCAN ? 4096 : BW_SCAN;
+    static_assert(QPT * 4 * BW_THREADS == BW_SCAN && BW_DOCS % BW_SCAN == 0 && BW_SCAN % SURV_CAP == 0 &&
+                  BW_DOCS <= 65536, "window shape");
+    static_assert(BW_CAP >= THR_TOPK_MAX + BW_THREADS, "top-k buffer");
+    __shared__ TermRange tr[8];      // .lds_off: the term's fixed share of the stage
+    __shared__ double t_idf[8];
+    __shared__ int64_t t_row[8];     // dense term: offset of its per-doc row; else -1
+    __shared__ int t_staged[8];      // postings staged for the coming pass
+    __shared__ int t_last[8];        // staged index of the last one when the list has more behind it, else -1
+    __shared__ int t_w[8];
+    __shared__ double acc_scale, th_glob;
+    __shared__ int p_thq, p_wmax, n_surv, cur_item, last_compact;
+    __shared__ double b_s[BW_CAP];
+    __shared__ int64_t b_id[BW_CAP];
+    __shared__ int b_cnt;
+    __shared__ double th_s;
+    __shared__ int64_t th_id;
+    __shared__ int32_t st_doc[BW_STAGE];
+    __shared__ uint8_t st_imp[BW_STAGE];
+    __shared__ uint32_t acc[ACC_WORDS];
+    __shared__ uint16_t surv[SURV_CAP];
+
+    const int n_items = ctl[0];
+    if (ctl[3] == 0) return;   // no query of the batch holds a dense term
+    BlockTopK<BW_CAP, BW_THREADS> tk;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[2], 1);
+        __syncthreads();
+        const int item = cur_item;
+        if (item >= n_items) break;
+        const int2 it = items[item];
+        const int q = it.x, sl = it.y;
+        if (q_long[q] >= 0) continue;   // bm25_topk_kernel's
+        const int S = q_S[q];
+        const int nt = q_nt[q];
+        const int qc = query_coll ? query_coll[q] : -1;
+        const int64_t D0 = bm_window_edge(n_docs, sl, S), D1 = bm_window_edge(n_docs, sl + 1, S);
+        if ((int)threadIdx.x < nt) {
+            const int slot = threadIdx.x;
+            const int term = q_terms[(int64_t)q * max_terms + slot];
+            const int64_t lo = rowptr[term];
+            const int ds = dense_slot[term];
+            const int start = ipos[((int64_t)item * max_terms + slot) * 2];
+            const int end = ipos[((int64_t)item * max_terms + slot) * 2 + 1];
+            tr[slot].lo = lo + start;
+            tr[slot].len = ds >= 0 ? 0 : end - start;
+            tr[slot].cur = 0;
+            tr[slot].sub = 0;
+            t_row[slot] = ds >= 0 ? (int64_t)ds * dense_stride : -1;
+            t_idf[slot] = idf[term];
+        }
+        if (threadIdx.x == 0) {
+            last_compact = 0;
+            const unsigned long long g0 = S > 1 ? __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            th_glob = g0 ? dkey_inv(g0) : -INFINITY;
+        }
+        BM_STAMP(0);
+        tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);   // includes a barrier
+        int n_sparse = 0;
+        for (int t = 0; t < nt; ++t) n_sparse += t_row[t] < 0 ? 1 : 0;
+        const int share = (BW_STAGE / (n_sparse > 0 ? n_sparse : 1)) & ~3;
+        if ((int)threadIdx.x < nt) {   // a term's fixed share of the stage
+            int rank = 0;
+            for (int e = 0; e < (int)threadIdx.x; ++e) rank += t_row[e] < 0 ? 1 : 0;
+            tr[threadIdx.x].lds_off = rank * share;
+        }
+        if (threadIdx.x == 0) {   // integer weights of the quantised impacts (see bm25_topk_kernel)
+            const double c = (k1 + 1.0) / 255.0;
+            double sum = 0.0;
+            for (int t = 0; t < nt; ++t) sum += t_idf[t] * c;
+            const double scale = 248.0 / sum;
+            for (int t = 0; t < nt; ++t) {
+                const int w = (int)ceil(t_idf[t] * c * scale);
+                t_w[t] = w < 1 ? 1 : w;
+            }
+            acc_scale = scale;
+        }
+        __syncthreads();
+        // what the coming pass (from ``cursor``) needs: its window, its threshold in accumulator
+        // units, and per list the postings to stage -- about twice the window's expected share of
+        // what is left of the list, at least 64, at most the term's share of the stage
+        auto prepare = [&](int64_t cursor) {
+            const bool have_local = b_cnt >= k && th_s > -INFINITY;
+            const bool have_th = have_local || th_glob > -INFINITY;
+            // without a threshold every doc that holds a term is scored in full: a short window gets one
+            const int wmax = have_th || S == 1 ? BW_DOCS : BW_DOCS / 8;
+            if (threadIdx.x == 0) {
+                double th = have_local ? th_s : -INFINITY;
+                th = th_glob > th ? th_glob : th;
+                const double tq = have_th ? floor(th * acc_scale * (1.0 - 1e-12)) : 0.0;
+                p_thq = tq < 0.0 ? 0 : tq > 70000.0 ? 70000 : (int)tq;
+                p_wmax = wmax;
+                n_surv = 0;
+            }
+            if ((int)threadIdx.x < nt) {
+                const int t = threadIdx.x;
+                int quota = 0;
+                if (t_row[t] < 0) {
+                    const int rem = tr[t].len - tr[t].cur;
+                    const float exp2 = 2.0f * (float)rem * (float)wmax / (float)(D1 - cursor) + 64.0f;
+                    quota = exp2 < (float)share ? (int)exp2 : share;
+                    quota = quota < rem ? quota : rem;
+                    t_last[t] = quota > 0 && quota < rem ? tr[t].lds_off + quota - 1 : -1;
+                } else {
+                    t_last[t] = -1;
+                }
+                t_staged[t] = quota;
+            }
+        };
+        int64_t cursor = D0;
+        prepare(cursor);
+        __syncthreads();
+        BM_STAMP(1);
+        while (cursor < D1) {
+            const int wmax = p_wmax;
+            // ---- dense terms: 4 docs per load, straight into registers ----
+            auto dense_sums = [&](uint32_t (&dsum)[2 * QPT], int h0) {   // docs [h0, h0 + BW_SCAN) of the window
+#pragma unroll
+                for (int j = 0; j < 2 * QPT; ++j) dsum[j] = 0u;
+                for (int t = 0; t < nt; ++t) {
+                    const int64_t row = t_row[t];
+                    if (row < 0) continue;
+                    const uint32_t wt = (uint32_t)t_w[t];
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(dense_imp + row + cursor + h0);   // a multiple of 4
+                    uint32_t v[QPT];
+#pragma unroll
+                    for (int j = 0; j < QPT; ++j) {
+                        const int dw = j * BW_THREADS + (int)threadIdx.x;
+                        v[j] = h0 + 4 * dw < wmax ? src[dw] : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < QPT; ++j) {
+                        dsum[2 * j] += (v[j] & 0xFFu) * wt + ((((v[j] >> 8) & 0xFFu) * wt) << 16);
+                        dsum[2 * j + 1] += ((v[j] >> 16) & 0xFFu) * wt + (((v[j] >> 24) * wt) << 16);
+                    }
+                }
+            };
+            uint32_t dsum0[2 * QPT];
+            dense_sums(dsum0, 0);
+            // ---- the other terms: stage their next postings, ids and impacts ----
+            unsigned long long gth = 0ull;
+            if (threadIdx.x == 0 && S > 1)
+                gth = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_sparse > 0) {
+                for (int t = 0; t < nt; ++t) {
+                    const int n = t_staged[t];
+                    if (n == 0) continue;
+                    const int64_t at = tr[t].lo + tr[t].cur;
+                    const int32_t* src = post_doc + at;
+                    const uint8_t* simp = post_imp + at;
+                    const int off = tr[t].lds_off;
+                    for (int i = threadIdx.x; i < n; i += BW_THREADS) {
+                        st_doc[off + i] = src[i];
+                        st_imp[off + i] = simp[i];
+                    }
+                }
+            }
+            if (threadIdx.x == 0 && S > 1) th_glob = gth ? dkey_inv(gth) : -INFINITY;
+            __syncthreads();
+            BM_STAMP(3);
+            // the pass ends where the window, the slice or the first list's staged run ends (a run of
+            // >= 64 docs: always past the cursor); a multiple of 4 unless it is the slice's end
+            int64_t end = cursor + wmax < D1 ? cursor + wmax : D1;
+            if (n_sparse > 0) {
+                for (int t = 0; t < nt; ++t) {
+                    const int l = t_last[t];
+                    if (l >= 0) {
+                        const int64_t hi = (int64_t)st_doc[l] + 1;
+                        end = hi < end ? hi : end;
+                    }
+                }
+            }
+            if (end < D1) end &= ~(int64_t)3;
+            const int w = (int)(end - cursor);
+            const double thg = th_glob;
+            auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
+            if (n_sparse > 0) {
+                for (int i = threadIdx.x; 2 * i < w; i += BW_THREADS) acc[i] = 0u;
+                __syncthreads();
+                BM_STAMP(4);
+                for (int t = 0; t < nt; ++t) {
+                    const int n = __builtin_amdgcn_readfirstlane(t_staged[t]);
+                    if (n == 0) continue;
+                    const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
+                    const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane(t_w[t]);
+                    for (int i = threadIdx.x; i < n; i += BW_THREADS) {
+                        const int64_t d = st_doc[off0 + i];
+                        if (d < end) {
+                            const int slot = (int)(d - cursor);
+                            atomicAdd(&acc[slot >> 1], ((uint32_t)st_imp[off0 + i] * wt) << ((slot & 1) << 4));
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            BM_STAMP(12);
+            BM_COUNT(14, 1);
+            // ---- scan: the docs whose bound reaches the threshold ----
+            const uint32_t thq = (uint32_t)p_thq;
+            auto scan = [&](int c0, int c1, const uint32_t (&dsum)[2 * QPT], int h0) {
+#pragma unroll
+                for (int j = 0; j < 2 * QPT; ++j) {
+                    const int wd = (h0 >> 1) + 2 * ((j >> 1) * BW_THREADS + (int)threadIdx.x) + (j & 1);
+                    const int s0 = 2 * wd;
+                    if (s0 >= c1 || s0 + 1 < c0 || s0 >= w) continue;
+                    const uint32_t v = dsum[j] + (n_sparse > 0 ? acc[wd] : 0u);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
+                        const int slot = s0 + u;
+                        if (a != 0u && a >= thq && slot >= c0 && slot < c1 && slot < w) {
+                            const int at = atomicAdd(&n_surv, 1);
+                            if (at < SURV_CAP) surv[at] = (uint16_t)slot;
+                        }
+                    }
+                }
+            };
+            auto phase2 = [&](int ns) {
+                for (int base = 0; base < ns; base += BW_THREADS) {
+                    const int j = base + threadIdx.x;
+                    bool keep = j < ns;
+                    double score = 0.0;
+                    int32_t d = 0;
+                    if (keep) {
+                        d = (int32_t)(cursor + surv[j]);
+                        // staged position of the doc in every other (non-dense) term.  (Ids behind this
+                        // pass's end are the next pass's: d is not among them.  The searches in lockstep,
+                        // eight wide and branch-free, were measured: slower, the registers they hold.)
+                        int pos[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            pos[e] = -1;
+                            if (e < nt && t_staged[e] > 0) pos[e] = find_doc(st_doc + tr[e].lds_off, t_staged[e], d);
+                        }
+                        if (qc != -1 && doc_coll[d] != qc) keep = false;
+                        if (keep) {
+                            const double dl = (double)doclen[d];
+                            int tfv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                tfv[e] = 0;
+                                if (e < nt) {
+                                    const int64_t row = t_row[e];
+                                    if (row >= 0) tfv[e] = (int)dense_tf[row + d];
+                                    else if (pos[e] >= 0) tfv[e] = post_tf[tr[e].lo + tr[e].cur + pos[e]];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (tfv[e] > 0)
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tfv[e], dl, avgdl, k1, b));
+                        }
+                    }
+                    push(keep, score, (int64_t)d);
+                }
+            };
+            scan(0, w, dsum0, 0);
+#pragma unroll 1
+            for (int h0 = BW_SCAN; h0 < w; h0 += BW_SCAN) {
+                uint32_t dsum1[2 * QPT];
+                dense_sums(dsum1, h0);
+                scan(0, w, dsum1, h0);
+            }
+            __syncthreads();
+            BM_STAMP(13);
+            const int ns = n_surv;
+            BM_COUNT(17, ns);
+            BM_COUNT(18, (ns + BW_THREADS - 1) / BW_THREADS);
+            if (ns <= SURV_CAP) {
+                phase2(ns);
+            } else {   // (passes without a threshold) SURV_CAP slots at a time
+                for (int c0 = 0; c0 < w; c0 += SURV_CAP) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) n_surv = 0;
+                    __syncthreads();
+                    {   // (the sums again: they are not kept across phase 2)
+                        const int h0 = c0 / BW_SCAN * BW_SCAN;
+                        uint32_t dsum1[2 * QPT];
+                        dense_sums(dsum1, h0);
+                        scan(c0, c0 + SURV_CAP, dsum1, h0);
+                    }
+                    __syncthreads();
+                    phase2(n_surv);
+                }
+            }
+            __syncthreads();
+            BM_STAMP(5);
+            if (b_cnt >= k && b_cnt - last_compact >= 64) {
+                BM_COUNT(15, 1);
+                tk.compact();
+                if (threadIdx.x == 0) {
+                    last_compact = b_cnt;
+                    if (S > 1 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+                }
+            }
+            // the postings this pass consumed (those of docs below its end), then the next pass's needs
+            if ((int)threadIdx.x < nt && t_staged[threadIdx.x] > 0)
+                tr[threadIdx.x].cur += count_below(st_doc + tr[threadIdx.x].lds_off, t_staged[threadIdx.x], end);
+            cursor = end;
+            if (cursor < D1) prepare(cursor);
+            __syncthreads();
+            BM_STAMP(10);
+        }
+        const int n = tk.finish();
+        if (S == 1) {
+            for (int i = threadIdx.x; i < k; i += BW_THREADS) {
+                out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
+                out_id[(int64_t)q * k + i] = i < n ? b_id[i] + id_base : -1;
+            }
+            if (threadIdx.x == 0) out_cnt[q] = n;
+        } else {
+            for (int i = threadIdx.x; i < n; i += BW_THREADS) {
+                slice_s[(int64_t)item * k + i] = b_s[i];
+                slice_id[(int64_t)item * k + i] = b_id[i] + id_base;
+            }
+            if (threadIdx.x == 0) {
+                slice_cnt[item] = n;
+                if (n >= k) atomicMax(&theta_glob[q], (unsigned long long)dkey(b_s[k - 1]));
+            }
+        }
+        BM_STAMP(11);
+#ifdef BM_STAMPS
+        ++stamp_items;
+#endif
+    }
+#ifdef BM_STAMPS
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < BM_NSTAMP; ++i) stamps[(int64_t)blockIdx.x * (BM_NSTAMP + 1) + i] = stamp_acc[i];
+        stamps[(int64_t)blockIdx.x * (BM_NSTAMP + 1) + BM_NSTAMP] = stamp_items;
+    }
+#endif
+}
+
 // The best k of a sliced query's per-slice lists (order: score desc, id asc -- the slices hold
 // disjoint docs, so there are no duplicates to resolve).
 constexpr int BMM_THREADS = 256, BMM_CAP = 512;
@@ -1047,7 +1472,7 @@ static BmLayout bm_layout(int nq, int mt, int k) {
     L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
     L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
 #ifdef BM_STAMPS
-    L.off_stamps = take(sizeof(unsigned long long) * 4096 * (BM_NSTAMP + 1));
+    L.off_stamps = take(sizeof(unsigned long long) * 2 * 4096 * (BM_NSTAMP + 1));
 #endif
     L.total = off;
     return L;
@@ -1094,6 +1519,30 @@ extern "C" int thr_bm25_bounds(const int64_t* rowptr, const int32_t* post_doc, c
     return launch_status();
 }
 
+extern "C" int64_t thr_bm25_dense_stride(int64_t n_docs) {
+    return n_docs > 0 ? ((n_docs + 15) & ~(int64_t)15) + BW_PAD : 0;
+}
+
+extern "C" int thr_bm25_dense_rows(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
+                                   const uint8_t* post_imp, const int32_t* terms, int n_terms,
+                                   int64_t n_docs, int64_t max_df, uint8_t* dense_imp, uint16_t* dense_tf,
+                                   thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!rowptr || !post_doc || !post_tf || !post_imp || !terms || !dense_imp || !dense_tf,
+                  THR_ERR_INVALID);
+    THR_RETURN_IF(n_terms <= 0 || n_docs <= 0 || max_df <= 0, THR_ERR_INVALID);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t stride = thr_bm25_dense_stride(n_docs);
+    hipError_t e = hipMemsetAsync(dense_imp, 0, (size_t)n_terms * stride, st);
+    if (e == hipSuccess) e = hipMemsetAsync(dense_tf, 0, sizeof(uint16_t) * (size_t)n_terms * stride, st);
+    if (e != hipSuccess) return (int)e;
+    int bx = (int)((max_df + 256 * 16 - 1) / (256 * 16));
+    bx = bx < 1 ? 1 : bx > 4096 ? 4096 : bx;
+    hipLaunchKernelGGL(bm25_dense_rows_kernel, dim3(bx, n_terms), dim3(256), 0, st, rowptr, post_doc, post_tf,
+                       post_imp, terms, stride, dense_imp, dense_tf);
+    return launch_status();
+}
+
 extern "C" size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k) {
     if (n_queries <= 0 || max_terms <= 0 || k <= 0) return 0;
     return bm_layout(n_queries, max_terms, k).total;
@@ -1101,7 +1550,9 @@ extern "C" size_t thr_bm25_workspace_bytes(int n_queries, int max_terms, int k) 
 
 extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, const int32_t* post_tf,
                              const float* doclen, const double* idf, const double* term_ub,
-                             const double* block_ub, const uint8_t* post_imp, double avgdl, double k1, double b,
+                             const double* block_ub, const uint8_t* post_imp, const int32_t* dense_slot,
+                             const uint8_t* dense_imp, const uint16_t* dense_tf, int64_t dense_stride,
+                             double avgdl, double k1, double b,
                              int64_t n_docs, int64_t n_vocab, int64_t id_base,
                              const int32_t* query_terms, int n_queries, int max_terms, int k,
                              int conjunctive, const int32_t* doc_coll, const int32_t* query_coll,
@@ -1115,6 +1566,10 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                       max_terms <= 0 || max_terms > THR_BM25_MAX_TERMS || !(avgdl > 0.0),
                   THR_ERR_INVALID);
     THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
+    // the dense rows come as a set, need the impacts, and are padded by one window
+    THR_RETURN_IF(dense_slot && (!dense_imp || !dense_tf || !post_imp || !term_ub ||
+                                 dense_stride < n_docs + BW_PAD || (dense_stride & 3)),
+                  THR_ERR_INVALID);
     const BmLayout L = bm_layout(n_queries, max_terms, k);
     THR_RETURN_IF(workspace_bytes < L.total, THR_ERR_WORKSPACE);
     char* ws = (char*)workspace;
@@ -1134,10 +1589,12 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
-    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1;
+    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1;
     if (small < 0) {
         const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
         use_imp = !(ei && ei[0] == '0');
+        ei = getenv("THR_BM25_DENSE");                // 0: every term through its postings (A/B knob)
+        use_dense = !(ei && ei[0] == '0');
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : (ev && ev[0] == 'h') ? 2 : 0;   // s(mall) / h(uge)
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
@@ -1149,14 +1606,41 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
     int grid = bm_num_cus() * (per_cu ? per_cu : (huge ? 1 : big ? 2 : 4));
     if (grid > L.cap) grid = L.cap;
+    const int32_t* dslot = (use_dense && use_imp) ? dense_slot : nullptr;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, ctl, q_tot, q_nt, q_S, q_item0,
-                       q_long, q_terms, items);
+                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, dslot, n_docs, ctl, q_tot,
+                       q_nt, q_S, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
-                       rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, ipos);
+                       rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, dslot, n_docs, ipos);
     int rc = launch_status();
     if (rc) return rc;
+    if (dslot) {
+        // queries with a dense term: doc-window passes over the per-doc rows (returns at once when
+        // the batch has none; the posting kernel below skips their items, and this one the others)
+        int wgrid = bm_num_cus() * 2;
+        if (wgrid > L.cap) wgrid = L.cap;
+#ifdef BM_STAMPS
+#define BW_STAMP_ARG , (unsigned long long*)(ws + L.off_stamps) + (size_t)4096 * (BM_NSTAMP + 1)
+#else
+#define BW_STAMP_ARG
+#endif
+#define THR_BM25_WINDOW_LAUNCH(W)                                                                        \
+    hipLaunchKernelGGL((bm25_window_kernel<512, 4096, W, 1024>), dim3(wgrid), dim3(512), 0, st, rowptr,  \
+                       post_doc, post_tf, doclen, idf, post_imp, dslot, dense_imp, dense_tf, dense_stride, \
+                       avgdl, k1, b, n_docs, id_base, max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S,  \
+                       q_long, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,      \
+                       out_ids, out_counts BW_STAMP_ARG)
+        static int wdocs = 0;
+        if (!wdocs) {
+            const char* ev = getenv("THR_BM25_WINDOW");   // docs per window pass, in thousands (A/B knob)
+            wdocs = ev && atoi(ev) == 8 ? 8192 : BW_PAD;
+        }
+        if (wdocs == 8192) THR_BM25_WINDOW_LAUNCH(8192);
+        else THR_BM25_WINDOW_LAUNCH(BW_PAD);
+#undef THR_BM25_WINDOW_LAUNCH
+        if ((rc = launch_status())) return rc;
+    }
     // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two workgroups per CU --
     // a four-term query of the bench (6.7 K postings) is one pass.  THR_BM25_SHAPE=small selects
     // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
@@ -1174,7 +1658,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
                        (term_ub && use_imp) ? post_imp : nullptr, avgdl, k1, b,                     \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
-                       q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,       \
+                       q_long, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores, \
                        out_ids, out_counts BM_STAMP_ARG)
     if (huge) THR_BM25_LAUNCH(1024, 16384, 8192, 2048);   // one 16-wave workgroup per CU, passes twice as long
     else if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024);
@@ -1186,20 +1670,23 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                                                "", "", "", "sparse path", "compact/advance", "finish",
                                                "mask / acc fill", "slot scan / middle search", "#acc passes", "#mask passes",
                                                "#postings masked", "#survivors", "#phase2 rounds", ""};
-        std::vector<unsigned long long> h((size_t)grid * (BM_NSTAMP + 1));
         hipStreamSynchronize(st);
-        hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double tot[BM_NSTAMP + 1] = {0};
-        for (int g = 0; g < grid; ++g)
-            for (int i = 0; i <= BM_NSTAMP; ++i) tot[i] += (double)h[(size_t)g * (BM_NSTAMP + 1) + i];
-        double all = 0;
-        for (int i = 0; i < 14; ++i) all += tot[i];
-        fprintf(stderr, "[bm25 stamps] %d queries, %d workgroups, %.0f items, %.0f cycles per workgroup:", n_queries, grid,
-                tot[BM_NSTAMP], all / grid);
-        for (int i = 0; i < 14; ++i)
-            if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
-        for (int i = 14; i < 19; ++i) fprintf(stderr, " %s %.0f", names[i], tot[i]);
-        fprintf(stderr, "\n");
+        for (int pass = 0; pass < (dslot ? 2 : 1); ++pass) {
+            const int g_n = pass ? bm_num_cus() * 2 : grid;
+            std::vector<unsigned long long> h((size_t)g_n * (BM_NSTAMP + 1));
+            hipMemcpy(h.data(), d_stamps + (size_t)pass * 4096 * (BM_NSTAMP + 1), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double tot[BM_NSTAMP + 1] = {0};
+            for (int g = 0; g < g_n; ++g)
+                for (int i = 0; i <= BM_NSTAMP; ++i) tot[i] += (double)h[(size_t)g * (BM_NSTAMP + 1) + i];
+            double all = 0;
+            for (int i = 0; i < 14; ++i) all += tot[i];
+            fprintf(stderr, "[bm25 stamps%s] %d queries, %d workgroups, %.0f items, %.0f cycles per workgroup:", pass ? " window kernel" : "", n_queries, g_n,
+                    tot[BM_NSTAMP], all / g_n);
+            for (int i = 0; i < 14; ++i)
+                if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
+            for (int i = 14; i < 19; ++i) fprintf(stderr, " %s %.0f", names[i], tot[i]);
+            fprintf(stderr, "\n");
+        }
     }
 #endif
     if ((rc = launch_status())) return rc;

@@ -120,7 +120,9 @@ class GpuIndex:
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
-                    k1: float = 1.2, b: float = 0.75) -> "GpuIndex":
+                    k1: float = 1.2, b: float = 0.75, dense_share: float = 0.125) -> "GpuIndex":
+        """``dense_share``: a term held by at least this share of the shard's docs also gets
+        per-doc rows of impacts / term frequencies (3 bytes per doc and term; 0 = none)."""
         self.lex = dict(rowptr=self._t(rowptr, torch.int64), post_doc=self._t(post_doc, torch.int32),
                         post_tf=self._t(post_tf, torch.int32), doclen=self._t(doclen, torch.float32),
                         idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b))
@@ -128,6 +130,8 @@ class GpuIndex:
         # per-term / per-128-posting score bounds for the WAND-style pruning of thr_bm25_topk
         L["bounds"] = N.bm25_bounds(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
                                     L["avgdl"], L["k1"], L["b"])
+        L["dense"] = N.bm25_dense_terms(L["rowptr"], L["post_doc"], L["post_tf"], L["bounds"][2],
+                                        int(L["doclen"].shape[0]), dense_share) if dense_share > 0 else None
         if self.n_docs == 0:
             self.n_docs = int(self.lex["doclen"].shape[0])
         return self
@@ -264,7 +268,7 @@ class GpuIndex:
         return self.doc_coll, qc
 
     def bm25_search(self, query_terms: torch.Tensor, k: int, collections=None,
-                    conjunctive: bool = False, prune: bool = True):
+                    conjunctive: bool = False, prune: bool = True, dense_rows: bool = True):
         """collections: int32 [nq] collection id per query (-1 = unfiltered) or None."""
         L = self.lex
         qt = self._t(query_terms, torch.int32)
@@ -275,7 +279,8 @@ class GpuIndex:
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
                            L["avgdl"], qt, k, self.doc_base, L["k1"], L["b"],
                            bounds=L["bounds"] if prune else None, conjunctive=conjunctive,
-                           doc_coll=dc, query_coll=qc, workspace=self._ws_lex)
+                           doc_coll=dc, query_coll=qc, workspace=self._ws_lex,
+                           dense=L["dense"] if prune and dense_rows else None)
 
     def graph_search(self, query_seeds: torch.Tensor, k: int, hops: int = 2):
         G = self.graph
