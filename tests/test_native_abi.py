@@ -35,7 +35,7 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.thr_bm25_topk(None, None, None, None, None, None, None, None, None, None, None, 0, 1.0, 1.2, 0.75,
                              10, 5, 0, None, 1, 4, 10, 0, None, None, None, None, None, None, 0, None) == -1
     # dense-term rows: one window of zero padding behind the shard's docs, 16-byte aligned
-    assert lib.thr_bm25_dense_stride(1000) == 1008 + 16384 and lib.thr_bm25_dense_stride(0) == 0
+    assert lib.thr_bm25_dense_stride(1000) == 1008 + 65536 and lib.thr_bm25_dense_stride(0) == 0
     assert lib.thr_bm25_dense_rows(None, None, None, None, None, 1, 10, 5, None, None, None) == -1
     # the work decomposition's item list, slice edges and per-slice lists: grows with nq, terms, k
     assert lib.thr_bm25_workspace_bytes(2048, 4, 50) > (2048 + 8192) * 50 * 16

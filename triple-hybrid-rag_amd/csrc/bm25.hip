@@ -42,6 +42,8 @@ namespace thr {
 //   BM_WINDOW   doc slots of the mask path (BM_STAGE <= 3 * BM_WINDOW: the survivor list shares it)
 //   BM_CAP      BlockTopK buffer (>= k + BM_THREADS)
 
+typedef unsigned short bm_u16x2 __attribute__((ext_vector_type(2)));
+
 struct TermRange {
     int64_t lo;   // first posting of the term
     int len;      // postings of the term
@@ -156,13 +158,19 @@ __global__ __launch_bounds__(256) void bm25_dense_rows_kernel(
 //   bm25_topk_kernel   persistent workgroups pull items from ctl[1];
 //   bm25_merge_kernel  per query with S_q > 1: the best k of its slices' lists.
 constexpr int BM_MAX_SLICES = 128;
-constexpr int BW_PAD = 16384;          // docs per window of bm25_window_kernel = zero padding of a dense row
-constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = n_queries + this
+constexpr int BW_DOCS0 = 16384;        // docs per window of bm25_window_kernel when walked terms' docs are left out
+constexpr int BW_PAD = 65536;          // ... when there are none = zero padding of a dense row
+constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = 2 * n_queries + this
 constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
 constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
                                        // call spreads its 75 K postings over nine workgroups
 constexpr int PLAN_THREADS = 1024;
 
+__device__ __forceinline__ int bm_slices(long long tot, long long target);
+// stage-A slices of a query with dense terms: none when its other terms have no posting
+__device__ __forceinline__ int bm_slices_a(long long sparse, long long target) {
+    return sparse > 0 ? bm_slices(sparse, target) : 0;
+}
 __device__ __forceinline__ int bm_slices(long long tot, long long target) {
     if (tot <= target) return 1;   // (a query of at most one slice's postings is one work item)
     const long long s = (tot + target - 1) / target;
@@ -177,9 +185,10 @@ __device__ __forceinline__ int64_t bm_window_edge(int64_t n_docs, int s, int S) 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
     int nq, int mt, int cap, int conjunctive, int n_slots, int target_max,
-    const int32_t* __restrict__ dense_slot, int64_t n_docs, int32_t* __restrict__ ctl,
-    int64_t* __restrict__ q_tot,
-    int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_item0,
+    const int32_t* __restrict__ dense_slot, const double* __restrict__ term_ub, int64_t n_docs,
+    int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot, double* __restrict__ q_dub,
+    int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_SA,
+    int32_t* __restrict__ q_pmask, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
     __shared__ int red[PLAN_THREADS];
     const int per = (nq + PLAN_THREADS - 1) / PLAN_THREADS;
@@ -187,36 +196,90 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int q1 = q0 + per < nq ? q0 + per : nq;
     for (int q = q0; q < q1; ++q) {
         int nt = 0, lng = 0;
-        long long tot = 0, best = -1, sparse = 0;
+        long long tot = 0, best = -1;
         bool dead = false;   // AND mode: a term outside the vocabulary is held by no doc
-        bool dense = false;
+        uint32_t cap_mask = 0;   // valid terms (first 8) that have per-doc rows
         for (int j = 0; j < mt; ++j) {
             const int term = query_terms[(int64_t)q * mt + j];
             if (term >= n_vocab && conjunctive) dead = true;
             if (term < 0 || term >= n_vocab) continue;   // padding / unknown term: no postings
             const long long len = rowptr[term + 1] - rowptr[term];
             if (len > best) { best = len; lng = nt; }
+            if (dense_slot && nt < 8 && dense_slot[term] >= 0) cap_mask |= 1u << nt;
             q_terms[(int64_t)q * mt + nt++] = term;
             tot += len;
-            if (dense_slot && dense_slot[term] >= 0) dense = true; else sparse += len;
         }
         if (dead) nt = 0, tot = 0;   // (nothing to score: the item writes an empty list)
-        // a query with a dense term (OR form, <= 8 terms) is the window kernel's: its work is one
-        // unit per doc of the shard plus the postings of its other terms, its slices are doc ranges
-        if (dense && !conjunctive && nt <= 8) {
-            lng = -1;
-            tot = n_docs + sparse;
-            atomicAdd(&ctl[3], 1);
+        // A query with dense terms (OR form, <= 8 terms) is split the MaxScore way.  Some of its
+        // terms are PROBED -- never walked, read from their per-doc rows where a doc is scored --,
+        // the others are WALKED.  Stage A walks the walked terms' postings (slices of those lists,
+        // bm25_topk_kernel<.., true>); stage B sweeps the shard's docs that hold none of the walked
+        // terms in doc windows (bm25_window_kernel) -- and is skipped when the probed terms' bounds
+        // together cannot reach stage A's threshold.  Which terms are probed only decides the
+        // cost, never the result: a term held by 1/64 of the docs always is (walking a posting costs
+        // ~20x what a sweep spends on a doc); rarer terms with rows are walked, rarest first, until
+        // the bounds of what is left sum to half the largest bound of a walked term held by >= 200
+        // docs (a guess of stage A's threshold from below: then the sweep is very likely skipped).
+        // q_SA = -1: not such a query; else the number of stage-A slices (the first q_SA of q_S).
+        uint32_t pmask = 0;
+        double dub = 0.0;
+        long long walked = tot;
+        if (cap_mask && !conjunctive && nt <= 8) {
+            double walk_ub = 0.0;
+            for (int t = 0; t < nt; ++t) {
+                const int term = q_terms[(int64_t)q * mt + t];
+                const long long len = rowptr[term + 1] - rowptr[term];
+                if ((cap_mask >> t) & 1u) {
+                    pmask |= 1u << t;
+                    dub += term_ub[term];
+                } else if (len >= 200 && term_ub[term] > walk_ub) {
+                    walk_ub = term_ub[term];
+                }
+            }
+            for (;;) {
+                if (!(dub > 0.5 * walk_ub)) break;
+                int pick = -1;
+                long long pick_len = 0;
+                for (int t = 0; t < nt; ++t) {   // the rarest probed term that may be walked
+                    if (!((pmask >> t) & 1u)) continue;
+                    const int term = q_terms[(int64_t)q * mt + t];
+                    const long long len = rowptr[term + 1] - rowptr[term];
+                    if (len * 64 >= n_docs) continue;   // (walking costs ~20x a sweep's per-doc work)
+                    if (pick < 0 || len < pick_len) { pick = t; pick_len = len; }
+                }
+                if (pick < 0) break;
+                const int term = q_terms[(int64_t)q * mt + pick];
+                pmask &= ~(1u << pick);
+                dub -= term_ub[term];
+                if (pick_len >= 200 && term_ub[term] > walk_ub) walk_ub = term_ub[term];
+            }
+            dub = 0.0;   // (summed again: no cancellation left over from the subtractions)
+            walked = 0;
+            best = -1;
+            for (int t = 0; t < nt; ++t) {
+                const int term = q_terms[(int64_t)q * mt + t];
+                const long long len = rowptr[term + 1] - rowptr[term];
+                if ((pmask >> t) & 1u) {
+                    dub += term_ub[term];
+                } else {
+                    walked += len;
+                    if (len > best) { best = len; lng = t; }   // (the longest WALKED list cuts the stage-A slices)
+                }
+            }
+            if (pmask) atomicAdd(&ctl[3], 1);
         }
+        q_SA[q] = pmask ? 0 : -1;                  // (slice counts: below, once the target is known)
+        q_pmask[q] = (int32_t)pmask;
+        q_dub[q] = dub;
+        q_tot[q] = pmask ? -(walked + 1) : tot;    // dense terms: -(postings of the walked terms + 1)
         q_nt[q] = nt;
         q_long[q] = lng;
-        q_tot[q] = tot;
     }
     // slice size: what gives every workgroup slot of the grid an item, between one pass and three
     __shared__ long long red64[PLAN_THREADS];
     {
-        long long t = 0;
-        for (int q = q0; q < q1; ++q) t += q_tot[q];
+        long long t = 0;   // (a stage-B sweep counts one unit per doc)
+        for (int q = q0; q < q1; ++q) t += q_tot[q] >= 0 ? q_tot[q] : -q_tot[q] - 1 + n_docs;
         red64[threadIdx.x] = t;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
@@ -229,7 +292,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     int total = 0, mine = 0;
     for (;;) {
         mine = 0;
-        for (int q = q0; q < q1; ++q) mine += bm_slices(q_tot[q], target);
+        for (int q = q0; q < q1; ++q)
+            mine += q_tot[q] >= 0 ? bm_slices(q_tot[q], target)
+                                  : bm_slices_a(-q_tot[q] - 1, target) + bm_slices(n_docs, target);
         red[threadIdx.x] = mine;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
@@ -238,7 +303,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         }
         total = red[0];
         __syncthreads();
-        if (total <= cap) break;   // (every query is one item once target >= its total: terminates)
+        if (total <= cap) break;   // (every query is one or two items once target >= its total: terminates)
         target *= 2;
     }
     // exclusive prefix of the per-thread item counts
@@ -257,7 +322,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     // slices are taken, and those start with the pruning already in force.
     int rest = (red[threadIdx.x] - mine) - q0;   // slices s >= 1 of the queries before this thread's
     for (int q = q0; q < q1; ++q) {
-        const int S = bm_slices(q_tot[q], target);
+        int S = 0;
+        if (q_tot[q] >= 0) {
+            S = bm_slices(q_tot[q], target);
+        } else {
+            const int SA = bm_slices_a(-q_tot[q] - 1, target);
+            q_SA[q] = SA;
+            S = SA + bm_slices(n_docs, target);
+        }
         q_S[q] = S;
         q_item0[q] = nq + rest - 1;
         items[q] = make_int2(q, 0);
@@ -270,31 +342,35 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
 __global__ __launch_bounds__(256) void bm25_edges_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ ctl, const int32_t* __restrict__ q_nt,
-    const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
+    const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA, const int32_t* __restrict__ q_long,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items, int mt,
-    const int32_t* __restrict__ dense_slot, int64_t n_docs, int32_t* __restrict__ ipos) {
+    const int32_t* __restrict__ q_pmask, int64_t n_docs, int32_t* __restrict__ ipos) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int item = (int)(g / mt), slot = (int)(g % mt);
     if (item >= ctl[0]) return;
     const int2 it = items[item];
-    const int q = it.x, s = it.y;
+    const int q = it.x;
     if (slot >= q_nt[q]) return;
     const int term = q_terms[(int64_t)q * mt + slot];
     const int64_t lo = rowptr[term];
     const int full = (int)(rowptr[term + 1] - lo);
     int start = 0, end = full;
-    const int S = q_S[q];
-    if (q_long[q] < 0) {
-        // window kernel: slice s is the doc range [bm_window_edge(s), bm_window_edge(s + 1));
-        // a dense term needs no postings, the others are cut by binary search
-        if (dense_slot[term] >= 0) {
-            start = end = 0;
-        } else if (S > 1) {
+    const int SA = q_SA[q];      // -1: an ordinary query; else its first SA slices are stage A
+    int S = q_S[q], s = it.y;
+    const bool sweep = SA >= 0 && s >= SA;
+    if (SA >= 0) {
+        if (sweep) s -= SA, S -= SA; else S = SA;
+    }
+    if (SA >= 0 && ((q_pmask[q] >> slot) & 1)) {
+        start = end = 0;         // a probed term is read from its per-doc rows
+    } else if (sweep) {
+        // stage B: slice s is the doc range [bm_window_edge(s), bm_window_edge(s + 1))
+        if (S > 1) {
             start = count_below(post_doc + lo, full, bm_window_edge(n_docs, s, S));
             end = count_below(post_doc + lo, full, bm_window_edge(n_docs, s + 1, S));
         }
     } else if (S > 1) {
-        const int L = q_long[q];
+        const int L = q_long[q];   // (stage A: the longest of the other terms' lists)
         const int tl = q_terms[(int64_t)q * mt + L];
         const int64_t lo_l = rowptr[tl], len_l = rowptr[tl + 1] - lo_l;
         // edge e of S: the (len * e / S)-th doc of the longest list (S > 1 only with > BM_TARGET_MIN
@@ -358,15 +434,17 @@ constexpr int BM_NSTAMP = 20;   // 0-13 phases (cycles), 14-19 counters
 #define BM_COUNT(i, v)
 #endif
 
-template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP>
+template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP, bool DP>
 __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
     const double* __restrict__ idf, const double* __restrict__ term_ub,
-    const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp, double avgdl, double k1,
-    double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
+    const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp,
+    const int32_t* __restrict__ dense_slot, const uint16_t* __restrict__ dense_tf, int64_t dense_stride,
+    double avgdl, double k1, double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
-    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
+    const int32_t* __restrict__ q_pmask,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
     const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
     double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
@@ -384,10 +462,15 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     __shared__ int t_staged[THR_BM25_MAX_TERMS];   // postings of the term staged in this pass
     __shared__ int t_subwin[THR_BM25_MAX_TERMS];   // ... of them inside the mask window
     __shared__ int t_prefix[THR_BM25_MAX_TERMS + 1];
+    // DP (stage A of a query with dense terms): those terms have no postings here; their per-doc
+    // rows are probed when a doc is scored, their bounds are added to every doc's bound
+    __shared__ int64_t t_row[8];    // dense term: offset of its per-doc row; else -1
+    __shared__ double p_dub;        // sum of the dense terms' term_ub
+    __shared__ int p_dmaxq;         // ... of their largest quantised impacts, in accumulator units
     __shared__ int t_w[8];          // accumulator path: integer weight of a term's quantised impacts
     __shared__ double acc_scale;    // ... accumulated bound = acc_scale * (real bound), rounded up
     __shared__ int p_acc, p_thq;    // this pass takes the accumulator path; its threshold in acc units
-    __shared__ int remaining, last_compact, n_surv, cur_item;
+    __shared__ int remaining, last_compact, n_surv, n_single, cur_item;
     __shared__ int64_t d_hi, d_lo, p_last;
     __shared__ double th_glob;
     __shared__ double b_s[BM_CAP];
@@ -412,16 +495,20 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     uint32_t* mask = scratch;
 
     const int n_items = ctl[0];
+    if (DP && ctl[3] == 0) return;   // no query of the batch holds a dense term
     BlockTopK<BM_CAP, BM_THREADS> tk;
     for (;;) {
         __syncthreads();   // the previous item's LDS state is no longer read
-        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[1], 1);
+        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[DP ? 4 : 1], 1);
         __syncthreads();
         const int item = cur_item;
         if (item >= n_items) break;   // (uniform: every workgroup of the grid ends here)
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
-        if (q_long[q] < 0) continue;   // a query with a dense term: bm25_window_kernel's
+        {   // a query with dense terms: its first q_SA slices are the DP build's, the rest bm25_window_kernel's
+            const int SA = q_SA[q];
+            if (DP ? !(SA >= 0 && sl < SA) : SA >= 0) continue;
+        }
         const int S = q_S[q];
         const int nt = q_nt[q];
         const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
@@ -441,6 +528,10 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             tr[slot].cur = 0;
             t_idf[slot] = idf[term];
             t_ub[slot] = term_ub ? term_ub[term] : INFINITY;
+            if (DP && slot < 8) {
+                const bool probed = (q_pmask[q] >> slot) & 1;
+                t_row[slot] = probed ? (int64_t)dense_slot[term] * dense_stride : -1;   // (its slice is empty: bm25_edges_kernel)
+            }
         }
         BM_STAMP(0);
         if (threadIdx.x == 0) {
@@ -472,6 +563,19 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     t_w[t] = w < 1 ? 1 : w;
                 }
                 acc_scale = scale;
+            }
+            if (DP) {
+                double dub = 0.0;
+                int dmaxq = 0;
+                for (int t = 0; t < nt; ++t) {
+                    if (t_row[t] < 0) continue;
+                    dub += t_ub[t];
+                    // the term's largest quantised impact: its bound / idf in steps of (k1+1)/255, as bm25_bounds_kernel rounds
+                    const double im = t_idf[t] > 0.0 ? ceil(t_ub[t] / t_idf[t] * (255.0 / (k1 + 1.0))) + 1.0 : 255.0;
+                    dmaxq += t_w[t] * (im > 255.0 || !(im >= 0.0) ? 255 : (int)im);
+                }
+                p_dub = dub;
+                p_dmaxq = dmaxq;
             }
         }
         __syncthreads();
@@ -579,6 +683,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 t_prefix[nt] = acc;
                 p_last = last;   // one past the last doc of the pass
                 n_surv = 0;
+                n_single = 0;
             }
             __syncthreads();
             BM_STAMP(4);
@@ -589,13 +694,25 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             const bool have_theta = have_local || thg > -INFINITY;
             // (a bound ub cannot make the top-k: it does not beat this item's threshold, or it is
             // below the threshold of the query's other slices)
-            auto pruned = [&](double ub) -> bool { return !(ub > theta) || ub < thg; };
+            // (DP: plus the dense terms' bounds -- added out of query-term order, so with a margin far
+            // above the rounding of an 8-term sum and far below anything that matters for pruning)
+            const double dub = DP ? p_dub : 0.0;
+            auto pruned = [&](double ub) -> bool {
+                if (DP) ub = (ub + dub) * (1.0 + 1e-12);
+                return !(ub > theta) || ub < thg;
+            };
+            // a dense term's contribution to doc d (DP), 0 when the doc does not hold it
+            auto dense_add = [&](int e, int32_t d, double dl, double& score) {
+                const int tfd = (int)dense_tf[t_row[e] + d];
+                if (tfd > 0) score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tfd, dl, avgdl, k1, b));
+            };
             auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
             const int64_t last = p_last;
             const int64_t first = d_lo;
             const bool use_acc = p_acc != 0;
             const bool masked = total > 0 && last - first <= (use_acc ? (int64_t)ACC_SLOTS : WIN);
             const uint32_t thq = (uint32_t)p_thq;
+            const uint32_t dmaxq = DP ? (uint32_t)p_dmaxq : 0u;
             uint16_t* surv = reinterpret_cast<uint16_t*>(masked ? scratch + ACC_WORDS : scratch);   // (ACC_WORDS == BM_WINDOW)
             auto slot_mask = [&](int slot) -> uint32_t {
                 const uint32_t v = mask[slot >> ms];
@@ -692,9 +809,11 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                         if (keep) {
                             const double dl = (double)doclen[d];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (wf[e] >= 0)
+                            for (int e = 0; e < 8; ++e) {
+                                if (DP && e < nt && t_row[e] >= 0) dense_add(e, d, dl, score);
+                                else if (wf[e] >= 0)
                                     score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)post_tf[tr[e].lo + tr[e].cur + wf[e]], dl, avgdl, k1, b));
+                            }
                             for (int e = 8 > t ? 8 : t; e < nt; ++e) {
                                 const int64_t w = where_far(e);
                                 if (w >= 0)
@@ -774,7 +893,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
                                 const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
-                                if (a != 0u && a >= thq) {
+                                if (a != 0u && a + dmaxq >= thq) {
                                     const int at = atomicAdd(&n_surv, 1);
                                     if (at < SURV_CAP) surv[at] = (uint16_t)((wd << 1) + u);
                                 }
@@ -896,9 +1015,11 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     if (qc != -1 && doc_coll[d] != qc) return false;
                     const double dl = (double)dl_own;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (wf[e] >= 0)
+                    for (int e = 0; e < 8; ++e) {
+                        if (DP && e < nt && t_row[e] >= 0) dense_add(e, d, dl, score);
+                        else if (wf[e] >= 0)
                             score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)(e == t ? tf_own : post_tf[tr[e].lo + tr[e].cur + wf[e]]), dl, avgdl, k1, b));
+                    }
                     for (int e = 8; e < nt; ++e) {
                         const int64_t w = far(e);
                         if (w >= 0)
@@ -927,21 +1048,26 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 uint16_t* work = reinterpret_cast<uint16_t*>(bloom ? scratch + nt * bwords : scratch);
                 // (n_surv is 0 here: it counts the work list now)
                 if (bloom) {
-                    // list by list: everything that depends on the term is uniform (scalar registers)
+                    // list by list: everything that depends on the term is uniform (scalar registers).
+                    // Nothing is scored in this sweep: a posting that is its doc's only one is held
+                    // against the threshold with its own quantised impact (plus, DP, the dense terms'
+                    // largest) and, when it may enter, listed -- from the BACK of the work list's
+                    // buffer, the postings to be searched from the front (together at most ``total``).
+                    const bool use_q = use_acc;   // (a threshold in accumulator units exists: p_thq)
                     for (int t = 0; t < nt; ++t) {
                         const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
                         const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
                         const int pre = __builtin_amdgcn_readfirstlane(t_prefix[t]);
-                        const int32_t* tf_t = post_tf + tr[t].lo + tr[t].cur;
-                        const double idf_t = t_idf[t], ub_t = t_ub[t];
-                        const bool single_ok = !(conjunctive && nt > 1);
+                        const uint32_t wt = use_q ? (uint32_t)__builtin_amdgcn_readfirstlane(t_w[t]) : 0u;
+                        const uint8_t* imp_t = post_imp + tr[t].lo + tr[t].cur;
+                        const double ub_t = t_ub[t];
+                        const double ubx_t = DP ? (ub_t + dub) * (1.0 + 1e-12) : ub_t;
+                        // (ub_t < threshold: no posting of this list can enter on its own)
+                        const bool single_ok = !(conjunctive && nt > 1) && !(ubx_t < th_s) && !(ubx_t < thg);
                         for (int base = 0; base < sub; base += BM_THREADS) {
                             const int i = base + (int)threadIdx.x;
-                            bool owner = false;
-                            double score = 0.0;
-                            int32_t d = 0;
                             if (i < sub) {
-                                d = st_doc[off0 + i];
+                                const int32_t d = st_doc[off0 + i];
                                 const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
                                 const uint32_t w = h >> 5, bit = 1u << (h & 31);
                                 bool alone = true;
@@ -949,14 +1075,43 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                                     if (e != t && (scratch[e * bwords + w] & bit)) alone = false;
                                 if (!alone) {
                                     work[atomicAdd(&n_surv, 1)] = (uint16_t)(pre + i);
-                                } else if (single_ok && !(ub_t < th_s) && !(ub_t < thg) && !(qc != -1 && doc_coll[d] != qc)) {
-                                    // (ub_t < threshold: no posting of this list can enter on its own)
-                                    owner = true;
-                                    score = __dadd_rn(score, bm25_contrib(idf_t, (double)tf_t[i], (double)doclen[d], avgdl, k1, b));
+                                } else if (single_ok && (!use_q || (uint32_t)imp_t[i] * wt + dmaxq >= thq)) {
+                                    work[total - 1 - atomicAdd(&n_single, 1)] = (uint16_t)(pre + i);
                                 }
                             }
-                            push(owner, score, (int64_t)d);
                         }
+                    }
+                    __syncthreads();
+                    // the listed singles, densely: collection filter, gathers, score, push
+                    const int ns1 = n_single;
+                    for (int base = 0; base < ns1; base += BM_THREADS) {
+                        const int j = base + (int)threadIdx.x;
+                        bool owner = j < ns1;
+                        double score = 0.0;
+                        int32_t d = 0;
+                        if (owner) {
+                            const int idx = work[total - 1 - j];
+                            int t = 0;
+                            while (idx >= t_prefix[t + 1]) ++t;
+                            const int off = idx - t_prefix[t];
+                            d = st_doc[tr[t].lds_off + off];
+                            if (qc != -1 && doc_coll[d] != qc) owner = false;
+                            if (owner) {
+                                const double dl = (double)doclen[d];
+                                const double tf_own = (double)post_tf[tr[t].lo + tr[t].cur + off];
+                                if (DP) {   // its own posting and the dense terms, in query-term order
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        if (e >= nt) continue;
+                                        if (t_row[e] >= 0) dense_add(e, d, dl, score);
+                                        else if (e == t) score = __dadd_rn(score, bm25_contrib(t_idf[e], tf_own, dl, avgdl, k1, b));
+                                    }
+                                } else {
+                                    score = __dadd_rn(score, bm25_contrib(t_idf[t], tf_own, dl, avgdl, k1, b));
+                                }
+                            }
+                        }
+                        push(owner, score, (int64_t)d);
                     }
                 } else {   // no room for the bits (many terms): every posting takes the searching sweep
                     for (int i = threadIdx.x; i < total; i += BM_THREADS) work[i] = (uint16_t)i;
@@ -1025,6 +1180,28 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 #endif
 }
 
+// Between stage A and stage B: the sweeps that are still needed.  The docs of a sweep hold none of
+// the query's other terms, so a score there is at most the sum of the dense terms' bounds (added
+// out of order: hence the margin); stage A is complete, and when that sum stays below its
+// threshold no doc of the sweep can enter the top-k -- the item is closed with an empty list.
+// The others are listed for bm25_window_kernel.
+__global__ __launch_bounds__(256) void bm25_sweep_filter_kernel(
+    int32_t* __restrict__ ctl, const int2* __restrict__ items, const int32_t* __restrict__ q_SA,
+    const double* __restrict__ q_dub, const unsigned long long* __restrict__ theta_glob,
+    int32_t* __restrict__ slice_cnt, int32_t* __restrict__ sweep_items) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= ctl[0]) return;
+    const int2 it = items[item];
+    const int SA = q_SA[it.x];
+    if (SA < 0 || it.y < SA) return;
+    const unsigned long long g = theta_glob[it.x];
+    if (g && q_dub[it.x] * (1.0 + 1e-12) < dkey_inv(g)) {
+        slice_cnt[item] = 0;   // (a threshold exists: the query has stage-A slices, the lists are merged)
+        return;
+    }
+    sweep_items[atomicAdd(&ctl[5], 1)] = item;
+}
+
 // ---------------------------------------------------------------------------------------------
 // bm25_window_kernel: the items of queries that hold a DENSE term (bm25_dense_rows_kernel).
 // An item is a doc range; a pass takes the next window of up to BW_DOCS docs.  The dense terms
@@ -1050,8 +1227,9 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
     const uint16_t* __restrict__ dense_tf, int64_t dense_stride, double avgdl, double k1, double b,
     int64_t n_docs, int64_t id_base, int max_terms, int k, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
-    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_long,
-    const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
+    const int32_t* __restrict__ q_pmask,
+    const int32_t* __restrict__ q_terms, const int2* __restrict__ items, const int32_t* __restrict__ sweep_items,
     const int32_t* __restrict__ ipos, unsigned long long* __restrict__ theta_glob,
     double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt
@@ -1089,27 +1267,26 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
     __shared__ uint32_t acc[ACC_WORDS];
     __shared__ uint16_t surv[SURV_CAP];
 
-    const int n_items = ctl[0];
-    if (ctl[3] == 0) return;   // no query of the batch holds a dense term
+    const int n_sweeps = ctl[5];   // (bm25_sweep_filter_kernel)
     BlockTopK<BW_CAP, BW_THREADS> tk;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[2], 1);
         __syncthreads();
-        const int item = cur_item;
-        if (item >= n_items) break;
+        if (cur_item >= n_sweeps) break;
+        const int item = sweep_items[cur_item];
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
-        if (q_long[q] >= 0) continue;   // bm25_topk_kernel's
-        const int S = q_S[q];
+        const int SA = q_SA[q];
+        const int S = q_S[q];              // (> 1: the item writes a slice list and shares the threshold)
         const int nt = q_nt[q];
         const int qc = query_coll ? query_coll[q] : -1;
-        const int64_t D0 = bm_window_edge(n_docs, sl, S), D1 = bm_window_edge(n_docs, sl + 1, S);
+        const int64_t D0 = bm_window_edge(n_docs, sl - SA, S - SA), D1 = bm_window_edge(n_docs, sl - SA + 1, S - SA);
         if ((int)threadIdx.x < nt) {
             const int slot = threadIdx.x;
             const int term = q_terms[(int64_t)q * max_terms + slot];
             const int64_t lo = rowptr[term];
-            const int ds = dense_slot[term];
+            const int ds = ((q_pmask[q] >> slot) & 1) ? dense_slot[term] : -1;   // a walked term: staged, its docs left out
             const int start = ipos[((int64_t)item * max_terms + slot) * 2];
             const int end = ipos[((int64_t)item * max_terms + slot) * 2 + 1];
             tr[slot].lo = lo + start;
@@ -1154,7 +1331,8 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
             const bool have_local = b_cnt >= k && th_s > -INFINITY;
             const bool have_th = have_local || th_glob > -INFINITY;
             // without a threshold every doc that holds a term is scored in full: a short window gets one
-            const int wmax = have_th || S == 1 ? BW_DOCS : BW_DOCS / 8;
+            // (no walked term: no accumulators, the window is as wide as 16-bit slot numbers allow)
+            const int wmax = !(have_th || S == 1) ? BW_DOCS / 8 : n_sparse == 0 ? BW_PAD : BW_DOCS;
             if (threadIdx.x == 0) {
                 double th = have_local ? th_s : -INFINITY;
                 th = th_glob > th ? th_glob : th;
@@ -1199,10 +1377,15 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                         const int dw = j * BW_THREADS + (int)threadIdx.x;
                         v[j] = h0 + 4 * dw < wmax ? src[dw] : 0u;
                     }
+                    // four impact bytes -> two words of two 16-bit sums: v_perm_b32 spreads the bytes,
+                    // v_pk_mad_u16 multiplies both lanes by the weight and adds (a sum stays below 2^16)
+                    const bm_u16x2 w2 = {(unsigned short)wt, (unsigned short)wt};
 #pragma unroll
                     for (int j = 0; j < QPT; ++j) {
-                        dsum[2 * j] += (v[j] & 0xFFu) * wt + ((((v[j] >> 8) & 0xFFu) * wt) << 16);
-                        dsum[2 * j + 1] += ((v[j] >> 16) & 0xFFu) * wt + (((v[j] >> 24) * wt) << 16);
+                        const bm_u16x2 lo = __builtin_bit_cast(bm_u16x2, __builtin_amdgcn_perm(0u, v[j], 0x0c010c00u));
+                        const bm_u16x2 hi = __builtin_bit_cast(bm_u16x2, __builtin_amdgcn_perm(0u, v[j], 0x0c030c02u));
+                        dsum[2 * j] = __builtin_bit_cast(uint32_t, (bm_u16x2)(lo * w2 + __builtin_bit_cast(bm_u16x2, dsum[2 * j])));
+                        dsum[2 * j + 1] = __builtin_bit_cast(uint32_t, (bm_u16x2)(hi * w2 + __builtin_bit_cast(bm_u16x2, dsum[2 * j + 1])));
                     }
                 }
             };
@@ -1266,6 +1449,8 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
             }
             BM_STAMP(12);
             BM_COUNT(14, 1);
+            BM_COUNT(16, w);
+            BM_COUNT(19, wmax);
             // ---- scan: the docs whose bound reaches the threshold ----
             const uint32_t thq = (uint32_t)p_thq;
             auto scan = [&](int c0, int c1, const uint32_t (&dsum)[2 * QPT], int h0) {
@@ -1274,12 +1459,15 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                     const int wd = (h0 >> 1) + 2 * ((j >> 1) * BW_THREADS + (int)threadIdx.x) + (j & 1);
                     const int s0 = 2 * wd;
                     if (s0 >= c1 || s0 + 1 < c0 || s0 >= w) continue;
-                    const uint32_t v = dsum[j] + (n_sparse > 0 ? acc[wd] : 0u);
+                    const uint32_t v = dsum[j];
+                    if ((v & 0xFFFFu) < thq && (v >> 16) < thq) continue;   // (nearly every word)
+                    const uint32_t other = n_sparse > 0 ? acc[wd] : 0u;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
                         const int slot = s0 + u;
-                        if (a != 0u && a >= thq && slot >= c0 && slot < c1 && slot < w) {
+                        // (a doc that holds one of the other terms was scored by stage A)
+                        if (a != 0u && a >= thq && ((other >> (u << 4)) & 0xFFFFu) == 0u && slot >= c0 && slot < c1 && slot < w) {
                             const int at = atomicAdd(&n_surv, 1);
                             if (at < SURV_CAP) surv[at] = (uint16_t)slot;
                         }
@@ -1294,15 +1482,6 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                     int32_t d = 0;
                     if (keep) {
                         d = (int32_t)(cursor + surv[j]);
-                        // staged position of the doc in every other (non-dense) term.  (Ids behind this
-                        // pass's end are the next pass's: d is not among them.  The searches in lockstep,
-                        // eight wide and branch-free, were measured: slower, the registers they hold.)
-                        int pos[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            pos[e] = -1;
-                            if (e < nt && t_staged[e] > 0) pos[e] = find_doc(st_doc + tr[e].lds_off, t_staged[e], d);
-                        }
                         if (qc != -1 && doc_coll[d] != qc) keep = false;
                         if (keep) {
                             const double dl = (double)doclen[d];
@@ -1313,7 +1492,6 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                                 if (e < nt) {
                                     const int64_t row = t_row[e];
                                     if (row >= 0) tfv[e] = (int)dense_tf[row + d];
-                                    else if (pos[e] >= 0) tfv[e] = post_tf[tr[e].lo + tr[e].cur + pos[e]];
                                 }
                             }
 #pragma unroll
@@ -1445,34 +1623,38 @@ __global__ __launch_bounds__(BMM_THREADS) void bm25_merge_kernel(
 
 // ---- workspace of thr_bm25_topk ----
 struct BmLayout {
-    size_t off_ctl, off_theta, off_tot, off_nt, off_S, off_item0, off_long, off_qterms, off_items,
+    size_t off_ctl, off_theta, off_tot, off_dub, off_sweep, off_nt, off_S, off_SA, off_pmask, off_item0, off_long, off_qterms, off_items,
         off_ipos, off_ss, off_sid, off_scnt, off_stamps, total;
     int cap;
 };
 static BmLayout bm_layout(int nq, int mt, int k) {
     BmLayout L;
-    L.cap = nq + BM_EXTRA_ITEMS;
+    L.cap = 2 * nq + BM_EXTRA_ITEMS;   // (a query with dense terms is at least two items: stage A, stage B)
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    L.off_ctl = take(sizeof(int32_t) * 4);                 // [0] items, [1] next item   } zeroed
+    L.off_ctl = take(sizeof(int32_t) * 8);                 // [0] items, [1] [2] [4] next item of a kernel, [3] queries with dense terms  } zeroed
     L.off_theta = take(sizeof(unsigned long long) * nq);   // shared thresholds (keys)   } per call
     L.off_tot = take(sizeof(int64_t) * nq);
+    L.off_dub = take(sizeof(double) * nq);
     L.off_nt = take(sizeof(int32_t) * nq);
     L.off_S = take(sizeof(int32_t) * nq);
+    L.off_SA = take(sizeof(int32_t) * nq);
+    L.off_pmask = take(sizeof(int32_t) * nq);
     L.off_item0 = take(sizeof(int32_t) * nq);
     L.off_long = take(sizeof(int32_t) * nq);
     L.off_qterms = take(sizeof(int32_t) * (size_t)nq * mt);
     L.off_items = take(sizeof(int2) * (size_t)L.cap);
+    L.off_sweep = take(sizeof(int32_t) * (size_t)L.cap);
     L.off_ipos = take(sizeof(int32_t) * 2 * (size_t)L.cap * mt);
     L.off_ss = take(sizeof(double) * (size_t)L.cap * k);
     L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
     L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
 #ifdef BM_STAMPS
-    L.off_stamps = take(sizeof(unsigned long long) * 2 * 4096 * (BM_NSTAMP + 1));
+    L.off_stamps = take(sizeof(unsigned long long) * 3 * 4096 * (BM_NSTAMP + 1));
 #endif
     L.total = off;
     return L;
@@ -1577,8 +1759,12 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* ctl = (int32_t*)(ws + L.off_ctl);
     unsigned long long* theta = (unsigned long long*)(ws + L.off_theta);
     int64_t* q_tot = (int64_t*)(ws + L.off_tot);
+    double* q_dub = (double*)(ws + L.off_dub);
+    int32_t* sweep_items = (int32_t*)(ws + L.off_sweep);
     int32_t* q_nt = (int32_t*)(ws + L.off_nt);
     int32_t* q_S = (int32_t*)(ws + L.off_S);
+    int32_t* q_SA = (int32_t*)(ws + L.off_SA);
+    int32_t* q_pmask = (int32_t*)(ws + L.off_pmask);
     int32_t* q_item0 = (int32_t*)(ws + L.off_item0);
     int32_t* q_long = (int32_t*)(ws + L.off_long);
     int32_t* q_terms = (int32_t*)(ws + L.off_qterms);
@@ -1608,16 +1794,47 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     if (grid > L.cap) grid = L.cap;
     const int32_t* dslot = (use_dense && use_imp) ? dense_slot : nullptr;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, dslot, n_docs, ctl, q_tot,
-                       q_nt, q_S, q_item0, q_long, q_terms, items);
+                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, dslot, term_ub, n_docs, ctl,
+                       q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
-                       rowptr, post_doc, ctl, q_nt, q_S, q_long, q_terms, items, max_terms, dslot, n_docs, ipos);
+                       rowptr, post_doc, ctl, q_nt, q_S, q_SA, q_long, q_terms, items, max_terms, q_pmask, n_docs, ipos);
     int rc = launch_status();
     if (rc) return rc;
+#ifdef BM_STAMPS
+    unsigned long long* d_stamps = (unsigned long long*)(ws + L.off_stamps);
+    if (grid > 4096) grid = 4096;
+#define BM_STAMP_ARG(DP) , d_stamps + (DP ? 2 : 0) * (size_t)4096 * (BM_NSTAMP + 1)
+#else
+#define BM_STAMP_ARG(DP)
+#endif
+    // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two workgroups per CU --
+    // a four-term query of the bench (6.7 K postings) is one pass.  THR_BM25_SHAPE=small selects
+    // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
+    // final sort) overlaps four ways, which wins when every list is short (2048 queries over lists
+    // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
+#define THR_BM25_LAUNCH(T, S, W, C, DP)                                                            \
+    hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C, DP>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
+                       post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
+                       (term_ub && use_imp) ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
+                       avgdl, k1, b,                                                                \
+                       id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
+                       q_SA, q_pmask, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt,    \
+                       out_scores, out_ids, out_counts BM_STAMP_ARG(DP))
+#define THR_BM25_LAUNCH_SHAPE(DP)                                                                     \
+    do {                                                                                              \
+        if (huge) THR_BM25_LAUNCH(1024, 16384, 8192, 2048, DP);   /* one 16-wave workgroup per CU */  \
+        else if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024, DP);                                     \
+        else THR_BM25_LAUNCH(256, 4096, 2048, 512, DP);                                               \
+    } while (0)
     if (dslot) {
-        // queries with a dense term: doc-window passes over the per-doc rows (returns at once when
-        // the batch has none; the posting kernel below skips their items, and this one the others)
+        // queries with dense terms: stage A (their other terms' postings, the dense rows probed), then
+        // stage B (doc-window sweeps, skipped where stage A's threshold rules them out).  Every kernel
+        // walks the one item list and takes the items that are its own.
+        THR_BM25_LAUNCH_SHAPE(true);
+        if ((rc = launch_status())) return rc;
+        hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, st, ctl, items,
+                           q_SA, q_dub, theta, slice_cnt, sweep_items);
         int wgrid = bm_num_cus() * 2;
         if (wgrid > L.cap) wgrid = L.cap;
 #ifdef BM_STAMPS
@@ -1629,41 +1846,19 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     hipLaunchKernelGGL((bm25_window_kernel<512, 4096, W, 1024>), dim3(wgrid), dim3(512), 0, st, rowptr,  \
                        post_doc, post_tf, doclen, idf, post_imp, dslot, dense_imp, dense_tf, dense_stride, \
                        avgdl, k1, b, n_docs, id_base, max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S,  \
-                       q_long, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores,      \
+                       q_SA, q_pmask, q_terms, items, sweep_items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores, \
                        out_ids, out_counts BW_STAMP_ARG)
         static int wdocs = 0;
         if (!wdocs) {
             const char* ev = getenv("THR_BM25_WINDOW");   // docs per window pass, in thousands (A/B knob)
-            wdocs = ev && atoi(ev) == 8 ? 8192 : BW_PAD;
+            wdocs = ev && atoi(ev) == 8 ? 8192 : BW_DOCS0;
         }
         if (wdocs == 8192) THR_BM25_WINDOW_LAUNCH(8192);
-        else THR_BM25_WINDOW_LAUNCH(BW_PAD);
+        else THR_BM25_WINDOW_LAUNCH(BW_DOCS0);
 #undef THR_BM25_WINDOW_LAUNCH
         if ((rc = launch_status())) return rc;
     }
-    // Block shape: 512 threads / 8192 staged ids per pass / 75 KiB of LDS, two workgroups per CU --
-    // a four-term query of the bench (6.7 K postings) is one pass.  THR_BM25_SHAPE=small selects
-    // 256 threads / 4096 ids / 39 KiB, four per CU: the fixed cost of an item (set-up, staging, the
-    // final sort) overlaps four ways, which wins when every list is short (2048 queries over lists
-    // of <= 200 postings: 0.075 ms against 0.124 ms) and loses otherwise.
-#ifdef BM_STAMPS
-    unsigned long long* d_stamps = (unsigned long long*)(ws + L.off_stamps);
-    if (grid > 4096) grid = 4096;
-#define BM_STAMP_ARG , d_stamps
-#else
-#define BM_STAMP_ARG
-#endif
-#define THR_BM25_LAUNCH(T, S, W, C)                                                                \
-    hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
-                       post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
-                       (term_ub && use_imp) ? post_imp : nullptr, avgdl, k1, b,                     \
-                       id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
-                       q_long, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores, \
-                       out_ids, out_counts BM_STAMP_ARG)
-    if (huge) THR_BM25_LAUNCH(1024, 16384, 8192, 2048);   // one 16-wave workgroup per CU, passes twice as long
-    else if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024);
-    else THR_BM25_LAUNCH(256, 4096, 2048, 512);
-#undef THR_BM25_LAUNCH
+    THR_BM25_LAUNCH_SHAPE(false);
 #ifdef BM_STAMPS
     {
         static const char* names[BM_NSTAMP] = {"item set-up", "init", "quotas", "staging", "edges/prefix", "phase 2 (+ chunk reset)",
@@ -1671,8 +1866,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                                                "mask / acc fill", "slot scan / middle search", "#acc passes", "#mask passes",
                                                "#postings masked", "#survivors", "#phase2 rounds", ""};
         hipStreamSynchronize(st);
-        for (int pass = 0; pass < (dslot ? 2 : 1); ++pass) {
-            const int g_n = pass ? bm_num_cus() * 2 : grid;
+        for (int pass = 0; pass < (dslot ? 3 : 1); ++pass) {
+            const int g_n = pass == 1 ? bm_num_cus() * 2 : grid;
             std::vector<unsigned long long> h((size_t)g_n * (BM_NSTAMP + 1));
             hipMemcpy(h.data(), d_stamps + (size_t)pass * 4096 * (BM_NSTAMP + 1), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             double tot[BM_NSTAMP + 1] = {0};
@@ -1680,11 +1875,11 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                 for (int i = 0; i <= BM_NSTAMP; ++i) tot[i] += (double)h[(size_t)g * (BM_NSTAMP + 1) + i];
             double all = 0;
             for (int i = 0; i < 14; ++i) all += tot[i];
-            fprintf(stderr, "[bm25 stamps%s] %d queries, %d workgroups, %.0f items, %.0f cycles per workgroup:", pass ? " window kernel" : "", n_queries, g_n,
+            fprintf(stderr, "[bm25 stamps%s] %d queries, %d workgroups, %.0f items, %.0f cycles per workgroup:", pass == 1 ? " window kernel (stage B)" : pass == 2 ? " stage A" : "", n_queries, g_n,
                     tot[BM_NSTAMP], all / g_n);
             for (int i = 0; i < 14; ++i)
                 if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
-            for (int i = 14; i < 19; ++i) fprintf(stderr, " %s %.0f", names[i], tot[i]);
+            for (int i = 14; i < 20; ++i) fprintf(stderr, " %s %.0f", names[i][0] ? names[i] : "#wmax", tot[i]);
             fprintf(stderr, "\n");
         }
     }

@@ -80,6 +80,7 @@ class GpuIndex:
     AUTO_COPY_FRACTION = 0.25    # of the device's memory: every shard the f16 scans can index (2^25 rows)
     F16_MAX_ROWS = 1 << 25       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
     F16_MAX_REL_ERR = 2e-3       # ~8x the rounding error of rows in float16's normal range
+    DENSE_SHARE = 0.01           # lexical terms held by this share of the docs get per-doc rows
 
     def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
@@ -120,9 +121,12 @@ class GpuIndex:
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
-                    k1: float = 1.2, b: float = 0.75, dense_share: float = 0.125) -> "GpuIndex":
+                    k1: float = 1.2, b: float = 0.75, dense_share: Optional[float] = None) -> "GpuIndex":
         """``dense_share``: a term held by at least this share of the shard's docs also gets
-        per-doc rows of impacts / term frequencies (3 bytes per doc and term; 0 = none)."""
+        per-doc rows of impacts / term frequencies (3 bytes per doc and term; 0 = none;
+        default DENSE_SHARE, or the A/B knob THR_BM25_DENSE_SHARE)."""
+        if dense_share is None:
+            dense_share = float(os.environ.get("THR_BM25_DENSE_SHARE", self.DENSE_SHARE))
         self.lex = dict(rowptr=self._t(rowptr, torch.int64), post_doc=self._t(post_doc, torch.int32),
                         post_tf=self._t(post_tf, torch.int32), doclen=self._t(doclen, torch.float32),
                         idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b))
