@@ -346,10 +346,16 @@ def main():
             qd_ = torch.from_numpy(np.ascontiguousarray(q_)).cuda()
             post = int(sum(int(csr.df_local[t]) for row in q_ for t in row if t >= 0))
             ms_b = event_ms(lambda: index.bm25_search(qd_, 50), 5, torch)
+            ms_all = event_ms(lambda: index.bm25_search(qd_, 50, prune=False), 2, torch)
             by_b = post * 12 + nq * 64        # ids + term frequencies + doc lengths of every posting
+            # The default call prunes (exact MaxScore / WAND bounds: same bits): most postings of a
+            # stop-word query are never read, so bytes-of-every-posting / time is NOT its HBM rate --
+            # it is quoted as an equivalent only; the HBM-rate figure is the unpruned call's.
             bm[mix] = {"ms": round(ms_b, 3), "queries": nq, "postings_per_query": round(post / nq, 1),
-                       "algorithmic_GBps": round(by_b / ms_b / 1e6, 1),
-                       "frac_of_hbm_8TBps": round(by_b / ms_b / 1e6 / HBM_PEAK_GBPS, 4)}
+                       "ms_every_posting_scored": round(ms_all, 3),
+                       "every_posting_scored_GBps": round(by_b / ms_all / 1e6, 1),
+                       "every_posting_scored_frac_of_hbm_8TBps": round(by_b / ms_all / 1e6 / HBM_PEAK_GBPS, 4),
+                       "pruned_equivalent_GBps_not_a_traffic_figure": round(by_b / ms_b / 1e6, 1)}
         bm["mix_of_the_timed_configs"] = args.lexical_mix
         bm["mixes"] = {"survey": "4 term ids sampled in proportion to df (SURVEY 8d; stop words included)",
                        "no-stopwords": "the same draw without the terms held by more than 1 % of the docs"}

@@ -224,14 +224,21 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * edges, per-slice lists. */
 /* Dense terms (ABI 7).  A stop word's posting list is most of the corpus; walking it posting by
  * posting is the slowest way to learn that nearly all of its docs cannot make the top-k.  The
- * caller picks the terms held by a large share of the docs (the host layer: df >= n_docs / 8,
- * tf <= 65535, at most 512 of them), lists them in ``terms`` and gets, per term, one ROW of
- * thr_bm25_dense_stride(n_docs) entries: dense_imp[row][d] = post_imp of doc d's posting (0: the
- * doc does not hold the term), dense_tf[row][d] = its term frequency.  dense_slot [V] maps a
- * term to its row (-1: not dense).  Given to thr_bm25_topk, OR queries of <= 8 terms that hold a
- * dense term walk the shard in doc windows: the dense terms' impacts come as coalesced loads of
- * the rows, only the other terms' postings are staged; the survivors of the impact bound are
- * scored from dense_tf / post_tf with the same arithmetic.  Results are the same bits. */
+ * caller picks the terms held by a large share of the docs (the host layer: df >= 1 % of the
+ * shard's docs, tf <= 65535, at most 512 of them), lists them in ``terms`` and gets, per term, one
+ * ROW of thr_bm25_dense_stride(n_docs) entries: dense_imp[row][d] = post_imp of doc d's posting (0:
+ * the doc does not hold the term), dense_tf[row][d] = its term frequency.  3 bytes per doc and
+ * term.  dense_slot [V] maps a term to its row (-1: none).
+ * Given to thr_bm25_topk, an OR query of <= 8 terms that holds such terms is evaluated the
+ * MaxScore way, in two stages.  Stage A walks the postings of the query's OTHER terms only; where
+ * a doc is scored, the dense terms' frequencies are read from their rows (no search), and every
+ * bound carries the dense terms' largest impacts.  Stage B covers the docs that hold none of the
+ * other terms: their score is at most the sum of the dense terms' bounds, so when that sum stays
+ * below stage A's k-th best score -- the usual case: a stop word's idf is small -- the stage is
+ * skipped; otherwise the shard is swept in doc windows, the dense terms' impacts arriving as
+ * coalesced loads of the rows (no posting is staged for them), and the few docs whose summed
+ * bound reaches the threshold are scored from dense_tf.  Both stages use the oracle's arithmetic
+ * in query-term order: the results are the same bits as without the rows. */
 int64_t thr_bm25_dense_stride(int64_t n_docs);
 int thr_bm25_dense_rows(const int64_t *rowptr, const int32_t *post_doc, const int32_t *post_tf,
                         const uint8_t *post_imp, const int32_t *terms /* [n_terms] */, int n_terms,

@@ -59,8 +59,9 @@ def main():
         ms = timed(lambda: idx.bm25_search(qd, 50, prune=True))
         out[name] = {"queries": len(qt), "postings_per_query": round(post / len(qt), 1),
                      "ms_every_posting_scored": round(ms_all, 3), "ms_with_bounds": round(ms, 3),
-                     "algorithmic_GBps": round((post * 12 + len(qt) * 64) / ms / 1e6, 1),
-                     "frac_of_hbm_8TBps": round((post * 12 + len(qt) * 64) / ms / 1e6 / 8000.0, 4),
+                     # (bytes of EVERY posting over time: an HBM rate only for the unpruned call)
+                     "every_posting_scored_GBps": round((post * 12 + len(qt) * 64) / ms_all / 1e6, 1),
+                     "pruned_equivalent_GBps_not_a_traffic_figure": round((post * 12 + len(qt) * 64) / ms / 1e6, 1),
                      "bit_equal_to_oracle": f"{ok}/{len(sub)}"}
     print(json.dumps(out))
 

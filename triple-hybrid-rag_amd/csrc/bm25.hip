@@ -29,6 +29,13 @@
 // bounds come from binary searches in LDS and only the survivors touch memory.
 // Term frequencies and doc lengths are read only for the postings that need them.
 // Algorithmic bytes per query: sum_t df_t * (4 doc + 4 tf + 4 doclen) + T * 16.
+//
+// Stop words (ABI 7): terms held by a large share of the docs also have per-doc ROWS of
+// quantised impacts and term frequencies (bm25_dense_rows_kernel).  A query that holds such
+// terms is split the MaxScore way: stage A walks only its other terms' postings and PROBES the
+// rows where a doc is scored (bm25_topk_kernel<.., DP = true>); stage B sweeps the docs that hold
+// none of the other terms in doc windows over the rows (bm25_window_kernel) -- unless the dense
+// terms' bounds cannot reach stage A's threshold (bm25_sweep_filter_kernel), the usual case.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -470,7 +477,8 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     __shared__ int t_w[8];          // accumulator path: integer weight of a term's quantised impacts
     __shared__ double acc_scale;    // ... accumulated bound = acc_scale * (real bound), rounded up
     __shared__ int p_acc, p_thq;    // this pass takes the accumulator path; its threshold in acc units
-    __shared__ int remaining, last_compact, n_surv, n_single, cur_item;
+    __shared__ int remaining, last_compact, n_surv, n_single, p_boot_q, cur_item;
+    __shared__ int t_order[THR_BM25_MAX_TERMS];   // terms by descending term_ub
     __shared__ int64_t d_hi, d_lo, p_last;
     __shared__ double th_glob;
     __shared__ double b_s[BM_CAP];
@@ -553,6 +561,13 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
             int total = 0;
             for (int t = 0; t < nt; ++t) total += tr[t].len;
             remaining = total;
+            for (int t = 0; t < nt; ++t) t_order[t] = t;
+            for (int a = 1; a < nt; ++a) {   // (insertion sort, <= 32 terms)
+                const int ta = t_order[a];
+                int c = a;
+                for (; c > 0 && t_ub[t_order[c - 1]] < t_ub[ta]; --c) t_order[c] = t_order[c - 1];
+                t_order[c] = ta;
+            }
             if (acc_ok) {
                 const double c = (k1 + 1.0) / 255.0;
                 double sum = 0.0;
@@ -684,6 +699,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 p_last = last;   // one past the last doc of the pass
                 n_surv = 0;
                 n_single = 0;
+                p_boot_q = 0;
             }
             __syncthreads();
             BM_STAMP(4);
@@ -985,6 +1001,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     }
                     __syncthreads();
                 }
+                BM_STAMP(6);
                 auto lookup = [&](int e, int32_t d) -> int {   // index of d in list e's staged ids, or -1
                     if (bloom) {
                         const uint32_t h = ((uint32_t)d * 2654435761u) >> (32 - bl2);
@@ -1053,8 +1070,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     // against the threshold with its own quantised impact (plus, DP, the dense terms'
                     // largest) and, when it may enter, listed -- from the BACK of the work list's
                     // buffer, the postings to be searched from the front (together at most ``total``).
-                    const bool use_q = use_acc;   // (a threshold in accumulator units exists: p_thq)
-                    for (int t = 0; t < nt; ++t) {
+                    auto list_term = [&](int t, bool use_q, uint32_t thq_now) {
                         const int sub = __builtin_amdgcn_readfirstlane(tr[t].sub);
                         const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
                         const int pre = __builtin_amdgcn_readfirstlane(t_prefix[t]);
@@ -1075,43 +1091,89 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                                     if (e != t && (scratch[e * bwords + w] & bit)) alone = false;
                                 if (!alone) {
                                     work[atomicAdd(&n_surv, 1)] = (uint16_t)(pre + i);
-                                } else if (single_ok && (!use_q || (uint32_t)imp_t[i] * wt + dmaxq >= thq)) {
+                                } else if (single_ok && (!use_q || (uint32_t)imp_t[i] * wt + dmaxq >= thq_now)) {
                                     work[total - 1 - atomicAdd(&n_single, 1)] = (uint16_t)(pre + i);
                                 }
                             }
                         }
-                    }
-                    __syncthreads();
-                    // the listed singles, densely: collection filter, gathers, score, push
-                    const int ns1 = n_single;
-                    for (int base = 0; base < ns1; base += BM_THREADS) {
-                        const int j = base + (int)threadIdx.x;
-                        bool owner = j < ns1;
-                        double score = 0.0;
-                        int32_t d = 0;
-                        if (owner) {
-                            const int idx = work[total - 1 - j];
-                            int t = 0;
-                            while (idx >= t_prefix[t + 1]) ++t;
-                            const int off = idx - t_prefix[t];
-                            d = st_doc[tr[t].lds_off + off];
-                            if (qc != -1 && doc_coll[d] != qc) owner = false;
+                    };
+                    // the listed singles [from, to), densely: collection filter, gathers, score, push
+                    auto score_singles = [&](int from, int to) {
+                        for (int base = from; base < to; base += BM_THREADS) {
+                            const int j = base + (int)threadIdx.x;
+                            bool owner = j < to;
+                            double score = 0.0;
+                            int32_t d = 0;
                             if (owner) {
-                                const double dl = (double)doclen[d];
-                                const double tf_own = (double)post_tf[tr[t].lo + tr[t].cur + off];
-                                if (DP) {   // its own posting and the dense terms, in query-term order
+                                const int idx = work[total - 1 - j];
+                                int t = 0;
+                                while (idx >= t_prefix[t + 1]) ++t;
+                                const int off = idx - t_prefix[t];
+                                d = st_doc[tr[t].lds_off + off];
+                                if (qc != -1 && doc_coll[d] != qc) owner = false;
+                                if (owner) {
+                                    const double dl = (double)doclen[d];
+                                    const double tf_own = (double)post_tf[tr[t].lo + tr[t].cur + off];
+                                    if (DP) {   // its own posting and the dense terms, in query-term order
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) {
-                                        if (e >= nt) continue;
-                                        if (t_row[e] >= 0) dense_add(e, d, dl, score);
-                                        else if (e == t) score = __dadd_rn(score, bm25_contrib(t_idf[e], tf_own, dl, avgdl, k1, b));
+                                        for (int e = 0; e < 8; ++e) {
+                                            if (e >= nt) continue;
+                                            if (t_row[e] >= 0) dense_add(e, d, dl, score);
+                                            else if (e == t) score = __dadd_rn(score, bm25_contrib(t_idf[e], tf_own, dl, avgdl, k1, b));
+                                        }
+                                    } else {
+                                        score = __dadd_rn(score, bm25_contrib(t_idf[t], tf_own, dl, avgdl, k1, b));
                                     }
-                                } else {
-                                    score = __dadd_rn(score, bm25_contrib(t_idf[t], tf_own, dl, avgdl, k1, b));
                                 }
                             }
+                            push(owner, score, (int64_t)d);
                         }
-                        push(owner, score, (int64_t)d);
+                    };
+#if defined(BM_BOOT_NONE)
+                    const bool boot = false;
+#elif defined(BM_BOOT_ALL)
+                    const bool boot = acc_ok && !have_theta && nt > 1;
+#else
+                    const bool boot = !DP && acc_ok && !have_theta && nt > 1;
+#endif
+                    if (!boot) {
+                        // (use_acc: a threshold in accumulator units exists, p_thq)
+                        for (int t = 0; t < nt; ++t) list_term(t, use_acc, thq);
+                        __syncthreads();
+                        BM_STAMP(7);
+                        BM_COUNT(19, n_single);
+                        score_singles(0, n_single);
+                        BM_STAMP(8);
+                    } else {
+                        // No threshold yet (an item's first pass -- the only one of a short query): list by
+                        // list, the largest bound first, and a select after each, so that the later lists
+                        // (smaller bounds: the longer ones) are held against a threshold already.
+                        int done = 0;
+                        for (int oi = 0; oi < nt; ++oi) {
+                            list_term(t_order[oi], p_boot_q != 0, (uint32_t)p_thq);
+                            __syncthreads();
+                            BM_STAMP(7);
+                            const int upto = n_single;
+                            BM_COUNT(19, upto - done);
+                            score_singles(done, upto);
+                            done = upto;
+                            __syncthreads();
+                            BM_STAMP(8);
+                            if (b_cnt >= k && b_cnt - last_compact >= 64) {
+                                tk.compact();
+                                if (threadIdx.x == 0) {
+                                    last_compact = b_cnt;
+                                    if (S > 1 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+                                }
+                            }
+                            if (threadIdx.x == 0 && b_cnt >= k && th_s > -INFINITY) {
+                                const double th = th_glob > th_s ? th_glob : th_s;
+                                const double tq = floor(th * acc_scale * (1.0 - 1e-12));
+                                p_thq = tq < 0.0 ? 0 : tq > 70000.0 ? 70000 : (int)tq;
+                                p_boot_q = 1;
+                            }
+                            __syncthreads();
+                        }
                     }
                 } else {   // no room for the bits (many terms): every posting takes the searching sweep
                     for (int i = threadIdx.x; i < total; i += BM_THREADS) work[i] = (uint16_t)i;
@@ -1203,16 +1265,16 @@ __global__ __launch_bounds__(256) void bm25_sweep_filter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// bm25_window_kernel: the items of queries that hold a DENSE term (bm25_dense_rows_kernel).
-// An item is a doc range; a pass takes the next window of up to BW_DOCS docs.  The dense terms
-// add their quantised impacts straight from their per-doc rows into per-thread registers
-// (coalesced dword loads: 4 docs each); the other terms' postings of the window (doc ids and
-// impacts) are staged in LDS and added into 16-bit LDS accumulators as in bm25_topk_kernel's
-// accumulator path.  A doc whose total bound reaches the threshold survives; phase 2 reads its
-// term frequencies -- per-doc rows for the dense terms, the posting found by binary search among
-// the staged ids for the others -- and scores it with the oracle's arithmetic in query-term
-// order.  Same exactness argument as the accumulator path (the bound is >= acc_scale * score),
-// same top-k / threshold sharing / slice merge as bm25_topk_kernel.
+// bm25_window_kernel: stage B of a query with dense (probed) terms -- the docs of a doc range that
+// hold none of the query's walked terms (those were scored by stage A).
+// A pass takes the next window of docs: up to BW_DOCS when walked terms exist, 64 K when not.  The
+// probed terms add their quantised impacts straight from their per-doc rows into per-thread
+// registers (coalesced dword loads: 4 docs each, v_perm_b32 + v_pk_mad_u16 into two 16-bit sums
+// per word), BW_SCAN docs at a time; the walked terms' postings of the window are staged in LDS
+// and marked in 16-bit LDS slots, which take their docs out.  A doc whose summed bound reaches the
+// threshold survives; phase 2 reads its term frequencies from the rows and scores it with the
+// oracle's arithmetic in query-term order.  Same exactness argument as the accumulator path (the
+// bound is >= acc_scale * score), same top-k / threshold sharing / slice merge as bm25_topk_kernel.
 //
 // A pass is a chain of dependent round trips, not of bytes, so its steps are arranged to need
 // few of them: the next pass's quotas and threshold are computed in the tail of the current one
@@ -1862,7 +1924,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #ifdef BM_STAMPS
     {
         static const char* names[BM_NSTAMP] = {"item set-up", "init", "quotas", "staging", "edges/prefix", "phase 2 (+ chunk reset)",
-                                               "", "", "", "sparse path", "compact/advance", "finish",
+                                               "bloom build", "singles listed", "singles scored", "work list / boot select", "compact/advance", "finish",
                                                "mask / acc fill", "slot scan / middle search", "#acc passes", "#mask passes",
                                                "#postings masked", "#survivors", "#phase2 rounds", ""};
         hipStreamSynchronize(st);
@@ -1879,7 +1941,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                     tot[BM_NSTAMP], all / g_n);
             for (int i = 0; i < 14; ++i)
                 if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
-            for (int i = 14; i < 20; ++i) fprintf(stderr, " %s %.0f", names[i][0] ? names[i] : "#wmax", tot[i]);
+            for (int i = 14; i < 20; ++i) fprintf(stderr, " %s %.0f", names[i][0] ? names[i] : "#wmax|#singles", tot[i]);
             fprintf(stderr, "\n");
         }
     }
