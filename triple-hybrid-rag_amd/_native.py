@@ -387,15 +387,20 @@ def bm25_bounds(rowptr, post_doc, post_tf, doclen, idf, avgdl: float, k1: float 
 
 
 def bm25_dense_terms(rowptr, post_doc, post_tf, post_imp, n_docs: int, min_share: float = 0.125,
-                     max_terms: int = 512):
+                     max_terms: int = 512, max_bytes: int = 12 << 30):
     """Index set-up -> (dense_slot i32 [V], dense_imp u8 [T, stride], dense_tf u16 [T, stride],
     stride) for the terms held by at least ``min_share`` of the docs (the ``max_terms`` longest
     of them, term frequencies <= 65535), or None when there is none: per-doc rows of impacts and
-    term frequencies, so that thr_bm25_topk never walks a stop word's postings."""
+    term frequencies, so that thr_bm25_topk never walks a stop word's postings.  At most
+    ``max_bytes`` of rows (12 GiB: 400 terms of a 10M-doc shard)."""
     _dev(rowptr, torch.int64, "rowptr", 1)
     df = rowptr[1:] - rowptr[:-1]
     cand = torch.nonzero(df.to(torch.float64) >= min_share * n_docs).flatten()
     if cand.numel() == 0 or n_docs <= 0:
+        return None
+    # 3 bytes per doc and term: the longest lists first, as many as ``max_bytes`` holds
+    max_terms = min(max_terms, max_bytes // (3 * int(load().thr_bm25_dense_stride(n_docs))))
+    if max_terms <= 0:
         return None
     keep = []
     for t in cand[torch.argsort(df[cand], descending=True, stable=True)][:max_terms].tolist():

@@ -191,7 +191,7 @@ __device__ __forceinline__ int64_t bm_window_edge(int64_t n_docs, int s, int S) 
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max,
+    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max, int walk_div,
     const int32_t* __restrict__ dense_slot, const double* __restrict__ term_ub, int64_t n_docs,
     int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot, double* __restrict__ q_dub,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_SA,
@@ -205,18 +205,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         int nt = 0, lng = 0;
         long long tot = 0, best = -1;
         bool dead = false;   // AND mode: a term outside the vocabulary is held by no doc
-        uint32_t cap_mask = 0;   // valid terms (first 8) that have per-doc rows
+#pragma unroll 4
         for (int j = 0; j < mt; ++j) {
             const int term = query_terms[(int64_t)q * mt + j];
             if (term >= n_vocab && conjunctive) dead = true;
             if (term < 0 || term >= n_vocab) continue;   // padding / unknown term: no postings
-            const long long len = rowptr[term + 1] - rowptr[term];
-            if (len > best) { best = len; lng = nt; }
-            if (dense_slot && nt < 8 && dense_slot[term] >= 0) cap_mask |= 1u << nt;
             q_terms[(int64_t)q * mt + nt++] = term;
-            tot += len;
         }
-        if (dead) nt = 0, tot = 0;   // (nothing to score: the item writes an empty list)
+        if (dead) nt = 0;   // (nothing to score: the item writes an empty list)
         // A query with dense terms (OR form, <= 8 terms) is split the MaxScore way.  Some of its
         // terms are PROBED -- never walked, read from their per-doc rows where a doc is scored --,
         // the others are WALKED.  Stage A walks the walked terms' postings (slices of those lists,
@@ -230,50 +226,74 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         // q_SA = -1: not such a query; else the number of stage-A slices (the first q_SA of q_S).
         uint32_t pmask = 0;
         double dub = 0.0;
-        long long walked = tot;
-        if (cap_mask && !conjunctive && nt <= 8) {
-            double walk_ub = 0.0;
+        long long walked = 0;
+        if (nt <= 8) {
+            // everything about the (up to eight) terms in registers, the loads of all of them in flight
+            // together: this kernel is one workgroup, its time is the length of its load chains
+            long long len_[8];
+            double ub_[8];
+            uint32_t cap_mask = 0;   // terms that have per-doc rows
+            const bool rows = dense_slot && !conjunctive;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool on = t < nt;
+                const int term = on ? q_terms[(int64_t)q * mt + t] : 0;
+                len_[t] = on ? rowptr[term + 1] - rowptr[term] : 0;
+                ub_[t] = on && rows ? term_ub[term] : 0.0;
+                if (on && rows && dense_slot[term] >= 0) cap_mask |= 1u << t;
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                tot += len_[t];
+                if (t < nt && len_[t] > best) { best = len_[t]; lng = t; }
+            }
+            walked = tot;
+            if (cap_mask) {
+                double walk_ub = 0.0;
+                pmask = cap_mask;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if ((cap_mask >> t) & 1u) dub += ub_[t];
+                    else if (t < nt && len_[t] >= 200 && ub_[t] > walk_ub) walk_ub = ub_[t];
+                }
+                for (;;) {
+                    if (!(dub > 0.5 * walk_ub)) break;
+                    int pick = -1;
+                    long long pick_len = 0;
+                    double pick_ub = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {   // the rarest probed term that may be walked
+                        if (!((pmask >> t) & 1u)) continue;
+                        if (len_[t] * walk_div >= n_docs) continue;   // (walking costs ~20x a sweep's per-doc work)
+                        if (pick < 0 || len_[t] < pick_len) { pick = t; pick_len = len_[t]; pick_ub = ub_[t]; }
+                    }
+                    if (pick < 0) break;
+                    pmask &= ~(1u << pick);
+                    dub -= pick_ub;
+                    if (pick_len >= 200 && pick_ub > walk_ub) walk_ub = pick_ub;
+                }
+                dub = 0.0;   // (summed again: no cancellation left over from the subtractions)
+                walked = 0;
+                best = -1;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t >= nt) continue;
+                    if ((pmask >> t) & 1u) {
+                        dub += ub_[t];
+                    } else {
+                        walked += len_[t];
+                        if (len_[t] > best) { best = len_[t]; lng = t; }   // (the longest WALKED list cuts the stage-A slices)
+                    }
+                }
+                if (pmask) atomicAdd(&ctl[3], 1);
+            }
+        } else {
             for (int t = 0; t < nt; ++t) {
                 const int term = q_terms[(int64_t)q * mt + t];
                 const long long len = rowptr[term + 1] - rowptr[term];
-                if ((cap_mask >> t) & 1u) {
-                    pmask |= 1u << t;
-                    dub += term_ub[term];
-                } else if (len >= 200 && term_ub[term] > walk_ub) {
-                    walk_ub = term_ub[term];
-                }
+                if (len > best) { best = len; lng = t; }
+                tot += len;
             }
-            for (;;) {
-                if (!(dub > 0.5 * walk_ub)) break;
-                int pick = -1;
-                long long pick_len = 0;
-                for (int t = 0; t < nt; ++t) {   // the rarest probed term that may be walked
-                    if (!((pmask >> t) & 1u)) continue;
-                    const int term = q_terms[(int64_t)q * mt + t];
-                    const long long len = rowptr[term + 1] - rowptr[term];
-                    if (len * 64 >= n_docs) continue;   // (walking costs ~20x a sweep's per-doc work)
-                    if (pick < 0 || len < pick_len) { pick = t; pick_len = len; }
-                }
-                if (pick < 0) break;
-                const int term = q_terms[(int64_t)q * mt + pick];
-                pmask &= ~(1u << pick);
-                dub -= term_ub[term];
-                if (pick_len >= 200 && term_ub[term] > walk_ub) walk_ub = term_ub[term];
-            }
-            dub = 0.0;   // (summed again: no cancellation left over from the subtractions)
-            walked = 0;
-            best = -1;
-            for (int t = 0; t < nt; ++t) {
-                const int term = q_terms[(int64_t)q * mt + t];
-                const long long len = rowptr[term + 1] - rowptr[term];
-                if ((pmask >> t) & 1u) {
-                    dub += term_ub[term];
-                } else {
-                    walked += len;
-                    if (len > best) { best = len; lng = t; }   // (the longest WALKED list cuts the stage-A slices)
-                }
-            }
-            if (pmask) atomicAdd(&ctl[3], 1);
         }
         q_SA[q] = pmask ? 0 : -1;                  // (slice counts: below, once the target is known)
         q_pmask[q] = (int32_t)pmask;
@@ -1837,12 +1857,14 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
-    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1;
+    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1, walk_div = 64;
     if (small < 0) {
         const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
         use_imp = !(ei && ei[0] == '0');
         ei = getenv("THR_BM25_DENSE");                // 0: every term through its postings (A/B knob)
         use_dense = !(ei && ei[0] == '0');
+        ei = getenv("THR_BM25_WALK_DIV");             // a term with rows may be walked when held by < 1/this of the docs
+        if (ei && atoi(ei) > 0) walk_div = atoi(ei);
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : (ev && ev[0] == 'h') ? 2 : 0;   // s(mall) / h(uge)
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
@@ -1856,7 +1878,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     if (grid > L.cap) grid = L.cap;
     const int32_t* dslot = (use_dense && use_imp) ? dense_slot : nullptr;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, dslot, term_ub, n_docs, ctl,
+                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, walk_div, dslot, term_ub, n_docs, ctl,
                        q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
