@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void bm25_dense_rows_kernel(
 //   bm25_topk_kernel   persistent workgroups pull items from ctl[1];
 //   bm25_merge_kernel  per query with S_q > 1: the best k of its slices' lists.
 constexpr int BM_MAX_SLICES = 128;
-constexpr int BW_DOCS0 = 16384;        // docs per window of bm25_window_kernel when walked terms' docs are left out
-constexpr int BW_PAD = 65536;          // ... when there are none = zero padding of a dense row
-constexpr int BM_EXTRA_ITEMS = 8192;   // item list capacity = 2 * n_queries + this
+constexpr int BW_PAD = 65536;          // docs per window of bm25_window_kernel = zero padding of a dense row
+constexpr int BM_EXTRA_ITEMS = 16384;  // item list capacity = 2 * n_queries + this (8 K / 16 K / 32 K / 64 K measured on 256 and
+                                       // 2048 stop-word queries: 0.95 / 0.86 / 0.85 / 0.86 and 2.07 / 1.90 / 1.94 / 2.19 ms)
 constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
 constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
                                        // call spreads its 75 K postings over nine workgroups
@@ -184,9 +184,9 @@ __device__ __forceinline__ int bm_slices(long long tot, long long target) {
     return s < 1 ? 1 : s > BM_MAX_SLICES ? BM_MAX_SLICES : (int)s;
 }
 
-// first doc of slice s of S of a window-kernel query (even: the 16-bit loads of the dense rows)
+// first doc of slice s of S of a window-kernel query (a multiple of 4: the dword loads of the dense rows)
 __device__ __forceinline__ int64_t bm_window_edge(int64_t n_docs, int s, int S) {
-    return s >= S ? n_docs : (n_docs * s / S) & ~(int64_t)1;
+    return s >= S ? n_docs : (n_docs * s / S) & ~(int64_t)3;
 }
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
@@ -1287,24 +1287,20 @@ __global__ __launch_bounds__(256) void bm25_sweep_filter_kernel(
 // ---------------------------------------------------------------------------------------------
 // bm25_window_kernel: stage B of a query with dense (probed) terms -- the docs of a doc range that
 // hold none of the query's walked terms (those were scored by stage A).
-// A pass takes the next window of docs: up to BW_DOCS when walked terms exist, 64 K when not.  The
-// probed terms add their quantised impacts straight from their per-doc rows into per-thread
-// registers (coalesced dword loads: 4 docs each, v_perm_b32 + v_pk_mad_u16 into two 16-bit sums
-// per word), BW_SCAN docs at a time; the walked terms' postings of the window are staged in LDS
-// and marked in 16-bit LDS slots, which take their docs out.  A doc whose summed bound reaches the
-// threshold survives; phase 2 reads its term frequencies from the rows and scores it with the
-// oracle's arithmetic in query-term order.  Same exactness argument as the accumulator path (the
+// The range is taken in SEGMENTS of up to 256 K docs.  Per segment the walked terms' postings set
+// one bit per doc in an LDS bitmap (32 KiB): the docs to leave out.  The segment is then swept in
+// windows of up to 64 K docs: the probed terms add their quantised impacts straight from their
+// per-doc rows into per-thread registers (coalesced dword loads: 4 docs each, v_perm_b32 +
+// v_pk_mad_u16 into two 16-bit sums per word), BW_SCAN docs at a time; a doc whose summed bound
+// reaches the threshold survives; phase 2 drops the survivors whose bit is set, reads the others'
+// term frequencies from the rows and scores them with the oracle's arithmetic in query-term order.
+// Nothing is staged per window and no accumulator is kept in LDS: a pass is the row loads, the
+// scan, the (few) survivors and the select.  Same exactness argument as the accumulator path (the
 // bound is >= acc_scale * score), same top-k / threshold sharing / slice merge as bm25_topk_kernel.
-//
-// A pass is a chain of dependent round trips, not of bytes, so its steps are arranged to need
-// few of them: the next pass's quotas and threshold are computed in the tail of the current one
-// (next to the select), every thread derives the pass's end itself from the staged ids (no
-// "edges" step), and how many staged postings a pass consumed is counted off the critical path.
-template <int BW_THREADS, int BW_STAGE, int BW_DOCS, int BW_CAP>
+template <int BW_THREADS, int BW_SCAN, int BW_CAP>
 __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
-    const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
-    const double* __restrict__ idf, const uint8_t* __restrict__ post_imp,
+    const float* __restrict__ doclen, const double* __restrict__ idf,
     const int32_t* __restrict__ dense_slot, const uint8_t* __restrict__ dense_imp,
     const uint16_t* __restrict__ dense_tf, int64_t dense_stride, double avgdl, double k1, double b,
     int64_t n_docs, int64_t id_base, int max_terms, int k, const int32_t* __restrict__ doc_coll,
@@ -1323,30 +1319,27 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
     unsigned long long stamp_acc[BM_NSTAMP] = {0};
     unsigned long long stamp_last = __builtin_readcyclecounter(), stamp_items = 0;
 #endif
-    constexpr int ACC_WORDS = BW_DOCS / 2;            // two 16-bit doc accumulators per word
-    // the dense rows are summed and scanned BW_SCAN docs at a time (what a thread's registers hold)
-    constexpr int BW_SCAN = BW_DOCS < 8192 ? BW_DOCS : 8192;
-    constexpr int QPT = BW_SCAN / 4 / BW_THREADS;     // dwords of a dense row per thread and scan (4 docs each)
-    constexpr int SURV_CAP = 4096 < BW_SCAN ? 4096 : BW_SCAN;
-    static_assert(QPT * 4 * BW_THREADS == BW_SCAN && BW_DOCS % BW_SCAN == 0 && BW_SCAN % SURV_CAP == 0 &&
-                  BW_DOCS <= 65536, "window shape");
+    constexpr int BIT_WORDS = 8192;                   // the segment's bitmap: 256 K docs
+    constexpr int SEG_DOCS = BIT_WORDS * 32;
+    constexpr int QPT = BW_SCAN / 4 / BW_THREADS;     // dwords of a dense row per thread and scan step (4 docs each)
+    constexpr int SURV_CAP = 4096;
+    constexpr int CHUNK = 4 * BW_THREADS;             // walked postings looked at per step of the bitmap fill
+    static_assert(QPT * 4 * BW_THREADS == BW_SCAN && BW_PAD % BW_SCAN == 0 && BW_SCAN % SURV_CAP == 0 &&
+                  BW_PAD <= 65536 && SEG_DOCS % BW_PAD == 0, "window shape");
     static_assert(BW_CAP >= THR_TOPK_MAX + BW_THREADS, "top-k buffer");
-    __shared__ TermRange tr[8];      // .lds_off: the term's fixed share of the stage
+    __shared__ TermRange tr[8];      // walked terms: .lo / .len = the slice's postings, .cur = consumed by earlier segments
     __shared__ double t_idf[8];
-    __shared__ int64_t t_row[8];     // dense term: offset of its per-doc row; else -1
-    __shared__ int t_staged[8];      // postings staged for the coming pass
-    __shared__ int t_last[8];        // staged index of the last one when the list has more behind it, else -1
-    __shared__ int t_w[8];
+    __shared__ int64_t t_row[8];     // probed term: offset of its per-doc row; else -1
+    __shared__ int t_w[8], p_w[8];
+    __shared__ int64_t p_row[8];     // the probed terms' rows and weights, compactly
     __shared__ double acc_scale, th_glob;
-    __shared__ int p_thq, p_wmax, n_surv, cur_item, last_compact;
+    __shared__ int p_thq, p_wmax, n_surv, cur_item, last_compact, chunk_cnt;
     __shared__ double b_s[BW_CAP];
     __shared__ int64_t b_id[BW_CAP];
     __shared__ int b_cnt;
     __shared__ double th_s;
     __shared__ int64_t th_id;
-    __shared__ int32_t st_doc[BW_STAGE];
-    __shared__ uint8_t st_imp[BW_STAGE];
-    __shared__ uint32_t acc[ACC_WORDS];
+    __shared__ uint32_t bits[BIT_WORDS];
     __shared__ uint16_t surv[SURV_CAP];
 
     const int n_sweeps = ctl[5];   // (bm25_sweep_filter_kernel)
@@ -1368,31 +1361,28 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
             const int slot = threadIdx.x;
             const int term = q_terms[(int64_t)q * max_terms + slot];
             const int64_t lo = rowptr[term];
-            const int ds = ((q_pmask[q] >> slot) & 1) ? dense_slot[term] : -1;   // a walked term: staged, its docs left out
+            const int ds = ((q_pmask[q] >> slot) & 1) ? dense_slot[term] : -1;   // a walked term: its docs are left out
             const int start = ipos[((int64_t)item * max_terms + slot) * 2];
             const int end = ipos[((int64_t)item * max_terms + slot) * 2 + 1];
             tr[slot].lo = lo + start;
             tr[slot].len = ds >= 0 ? 0 : end - start;
             tr[slot].cur = 0;
-            tr[slot].sub = 0;
             t_row[slot] = ds >= 0 ? (int64_t)ds * dense_stride : -1;
             t_idf[slot] = idf[term];
         }
         if (threadIdx.x == 0) {
             last_compact = 0;
+            chunk_cnt = 0;
             const unsigned long long g0 = S > 1 ? __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED,
                                                                     __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             th_glob = g0 ? dkey_inv(g0) : -INFINITY;
         }
         BM_STAMP(0);
         tk.init(b_s, b_id, &b_cnt, &th_s, &th_id, k);   // includes a barrier
-        int n_sparse = 0;
-        for (int t = 0; t < nt; ++t) n_sparse += t_row[t] < 0 ? 1 : 0;
-        const int share = (BW_STAGE / (n_sparse > 0 ? n_sparse : 1)) & ~3;
-        if ((int)threadIdx.x < nt) {   // a term's fixed share of the stage
-            int rank = 0;
-            for (int e = 0; e < (int)threadIdx.x; ++e) rank += t_row[e] < 0 ? 1 : 0;
-            tr[threadIdx.x].lds_off = rank * share;
+        int n_walked = 0, np = 0;
+        for (int t = 0; t < nt; ++t) {
+            n_walked += t_row[t] < 0 && tr[t].len > 0 ? 1 : 0;
+            np += t_row[t] >= 0 ? 1 : 0;
         }
         if (threadIdx.x == 0) {   // integer weights of the quantised impacts (see bm25_topk_kernel)
             const double c = (k1 + 1.0) / 255.0;
@@ -1404,64 +1394,97 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                 t_w[t] = w < 1 ? 1 : w;
             }
             acc_scale = scale;
+            int i = 0;   // the probed terms, compactly: row and weight
+            for (int t = 0; t < nt; ++t)
+                if (t_row[t] >= 0) {
+                    p_row[i] = t_row[t];
+                    p_w[i++] = t_w[t];
+                }
         }
         __syncthreads();
-        // what the coming pass (from ``cursor``) needs: its window, its threshold in accumulator
-        // units, and per list the postings to stage -- about twice the window's expected share of
-        // what is left of the list, at least 64, at most the term's share of the stage
-        auto prepare = [&](int64_t cursor) {
-            const bool have_local = b_cnt >= k && th_s > -INFINITY;
-            const bool have_th = have_local || th_glob > -INFINITY;
-            // without a threshold every doc that holds a term is scored in full: a short window gets one
-            // (no walked term: no accumulators, the window is as wide as 16-bit slot numbers allow)
-            const int wmax = !(have_th || S == 1) ? BW_DOCS / 8 : n_sparse == 0 ? BW_PAD : BW_DOCS;
+        // what the coming pass needs: its window and its threshold in accumulator units
+        auto prepare = [&]() {
             if (threadIdx.x == 0) {
+                const bool have_local = b_cnt >= k && th_s > -INFINITY;
+                const bool have_th = have_local || th_glob > -INFINITY;
                 double th = have_local ? th_s : -INFINITY;
                 th = th_glob > th ? th_glob : th;
                 const double tq = have_th ? floor(th * acc_scale * (1.0 - 1e-12)) : 0.0;
                 p_thq = tq < 0.0 ? 0 : tq > 70000.0 ? 70000 : (int)tq;
-                p_wmax = wmax;
+                // without a threshold every doc that holds a term is scored in full: a short window gets one
+                p_wmax = have_th || S == 1 ? BW_PAD : 2048;
                 n_surv = 0;
             }
-            if ((int)threadIdx.x < nt) {
-                const int t = threadIdx.x;
-                int quota = 0;
-                if (t_row[t] < 0) {
-                    const int rem = tr[t].len - tr[t].cur;
-                    const float exp2 = 2.0f * (float)rem * (float)wmax / (float)(D1 - cursor) + 64.0f;
-                    quota = exp2 < (float)share ? (int)exp2 : share;
-                    quota = quota < rem ? quota : rem;
-                    t_last[t] = quota > 0 && quota < rem ? tr[t].lds_off + quota - 1 : -1;
-                } else {
-                    t_last[t] = -1;
-                }
-                t_staged[t] = quota;
-            }
         };
-        int64_t cursor = D0;
-        prepare(cursor);
-        __syncthreads();
         BM_STAMP(1);
-        while (cursor < D1) {
-            const int wmax = p_wmax;
-            // ---- dense terms: 4 docs per load, straight into registers ----
-            auto dense_sums = [&](uint32_t (&dsum)[2 * QPT], int h0) {   // docs [h0, h0 + BW_SCAN) of the window
-#pragma unroll
-                for (int j = 0; j < 2 * QPT; ++j) dsum[j] = 0u;
+        for (int64_t g0 = D0; g0 < D1; g0 += SEG_DOCS) {
+            const int64_t g1 = g0 + SEG_DOCS < D1 ? g0 + SEG_DOCS : D1;
+            // ---- the segment's docs that hold a walked term: one bit each ----
+            if (n_walked > 0) {
+                const int nw = (int)((g1 - g0 + 31) >> 5);
+                for (int i = threadIdx.x; i < nw; i += BW_THREADS) bits[i] = 0u;
+                __syncthreads();
                 for (int t = 0; t < nt; ++t) {
-                    const int64_t row = t_row[t];
-                    if (row < 0) continue;
-                    const uint32_t wt = (uint32_t)t_w[t];
-                    const uint32_t* src = reinterpret_cast<const uint32_t*>(dense_imp + row + cursor + h0);   // a multiple of 4
-                    uint32_t v[QPT];
+                    if (t_row[t] >= 0) continue;
+                    for (;;) {   // the list's next postings, CHUNK at a time, up to the segment's end (the list is doc-sorted)
+                        const int base = tr[t].cur, rem = tr[t].len - base;
+                        if (rem <= 0) break;
+                        const int n = rem < CHUNK ? rem : CHUNK;
+                        const int32_t* src = post_doc + tr[t].lo + base;
+                        int mine = 0;
+#pragma unroll
+                        for (int u = 0; u < CHUNK / BW_THREADS; ++u) {
+                            const int i = u * BW_THREADS + (int)threadIdx.x;
+                            if (i < n) {
+                                const int64_t d = src[i];
+                                if (d < g1) {
+                                    const uint32_t bit = (uint32_t)(d - g0);
+                                    atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+                                    ++mine;
+                                }
+                            }
+                        }
+                        if (mine) atomicAdd(&chunk_cnt, mine);
+                        __syncthreads();
+                        const int c = chunk_cnt;
+                        __syncthreads();
+                        if (threadIdx.x == 0) {
+                            tr[t].cur = base + c;
+                            chunk_cnt = 0;
+                        }
+                        __syncthreads();
+                        if (c < n) break;   // the rest of the list belongs to later segments
+                    }
+                }
+            }
+            prepare();
+            __syncthreads();
+            BM_STAMP(3);
+            int64_t cursor = g0;
+            while (cursor < g1) {
+                const int wmax = p_wmax;
+                const int64_t end = cursor + wmax < g1 ? cursor + wmax : g1;   // (g0, the window widths: multiples of 4)
+                const int w = (int)(end - cursor);
+                const double thg = th_glob;
+                auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
+                // (the other slices' threshold for the NEXT pass: requested now, read in the tail)
+                unsigned long long gth = 0ull;
+                if (threadIdx.x == 0 && S > 1)
+                    gth = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ---- probed terms: 4 docs per load, straight into registers ----
+                auto load_rows = [&](uint32_t (&v)[QPT], int i, int h0) {   // row i, docs [h0, h0 + BW_SCAN) of the window
+                    const uint32_t* src = reinterpret_cast<const uint32_t*>(dense_imp + p_row[i] + cursor + h0);   // a multiple of 4
 #pragma unroll
                     for (int j = 0; j < QPT; ++j) {
                         const int dw = j * BW_THREADS + (int)threadIdx.x;
-                        v[j] = h0 + 4 * dw < wmax ? src[dw] : 0u;
+                        v[j] = h0 + 4 * dw < w ? src[dw] : 0u;
                     }
-                    // four impact bytes -> two words of two 16-bit sums: v_perm_b32 spreads the bytes,
-                    // v_pk_mad_u16 multiplies both lanes by the weight and adds (a sum stays below 2^16)
-                    const bm_u16x2 w2 = {(unsigned short)wt, (unsigned short)wt};
+                };
+                // four impact bytes -> two words of two 16-bit sums: v_perm_b32 spreads the bytes,
+                // v_pk_mad_u16 multiplies both lanes by the weight and adds (a sum stays below 2^16)
+                auto add_rows = [&](uint32_t (&dsum)[2 * QPT], const uint32_t (&v)[QPT], int i) {
+                    const unsigned short wt = (unsigned short)p_w[i];
+                    const bm_u16x2 w2 = {wt, wt};
 #pragma unroll
                     for (int j = 0; j < QPT; ++j) {
                         const bm_u16x2 lo = __builtin_bit_cast(bm_u16x2, __builtin_amdgcn_perm(0u, v[j], 0x0c010c00u));
@@ -1469,168 +1492,144 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                         dsum[2 * j] = __builtin_bit_cast(uint32_t, (bm_u16x2)(lo * w2 + __builtin_bit_cast(bm_u16x2, dsum[2 * j])));
                         dsum[2 * j + 1] = __builtin_bit_cast(uint32_t, (bm_u16x2)(hi * w2 + __builtin_bit_cast(bm_u16x2, dsum[2 * j + 1])));
                     }
-                }
-            };
-            uint32_t dsum0[2 * QPT];
-            dense_sums(dsum0, 0);
-            // ---- the other terms: stage their next postings, ids and impacts ----
-            unsigned long long gth = 0ull;
-            if (threadIdx.x == 0 && S > 1)
-                gth = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n_sparse > 0) {
-                for (int t = 0; t < nt; ++t) {
-                    const int n = t_staged[t];
-                    if (n == 0) continue;
-                    const int64_t at = tr[t].lo + tr[t].cur;
-                    const int32_t* src = post_doc + at;
-                    const uint8_t* simp = post_imp + at;
-                    const int off = tr[t].lds_off;
-                    for (int i = threadIdx.x; i < n; i += BW_THREADS) {
-                        st_doc[off + i] = src[i];
-                        st_imp[off + i] = simp[i];
-                    }
-                }
-            }
-            if (threadIdx.x == 0 && S > 1) th_glob = gth ? dkey_inv(gth) : -INFINITY;
-            __syncthreads();
-            BM_STAMP(3);
-            // the pass ends where the window, the slice or the first list's staged run ends (a run of
-            // >= 64 docs: always past the cursor); a multiple of 4 unless it is the slice's end
-            int64_t end = cursor + wmax < D1 ? cursor + wmax : D1;
-            if (n_sparse > 0) {
-                for (int t = 0; t < nt; ++t) {
-                    const int l = t_last[t];
-                    if (l >= 0) {
-                        const int64_t hi = (int64_t)st_doc[l] + 1;
-                        end = hi < end ? hi : end;
-                    }
-                }
-            }
-            if (end < D1) end &= ~(int64_t)3;
-            const int w = (int)(end - cursor);
-            const double thg = th_glob;
-            auto push = [&](bool ok, double sc, int64_t d) { tk.push(ok && !(sc < thg), sc, d); };
-            if (n_sparse > 0) {
-                for (int i = threadIdx.x; 2 * i < w; i += BW_THREADS) acc[i] = 0u;
-                __syncthreads();
-                BM_STAMP(4);
-                for (int t = 0; t < nt; ++t) {
-                    const int n = __builtin_amdgcn_readfirstlane(t_staged[t]);
-                    if (n == 0) continue;
-                    const int off0 = __builtin_amdgcn_readfirstlane(tr[t].lds_off);
-                    const uint32_t wt = (uint32_t)__builtin_amdgcn_readfirstlane(t_w[t]);
-                    for (int i = threadIdx.x; i < n; i += BW_THREADS) {
-                        const int64_t d = st_doc[off0 + i];
-                        if (d < end) {
-                            const int slot = (int)(d - cursor);
-                            atomicAdd(&acc[slot >> 1], ((uint32_t)st_imp[off0 + i] * wt) << ((slot & 1) << 4));
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            BM_STAMP(12);
-            BM_COUNT(14, 1);
-            BM_COUNT(16, w);
-            BM_COUNT(19, wmax);
-            // ---- scan: the docs whose bound reaches the threshold ----
-            const uint32_t thq = (uint32_t)p_thq;
-            auto scan = [&](int c0, int c1, const uint32_t (&dsum)[2 * QPT], int h0) {
+                };
+                auto dense_sums = [&](uint32_t (&dsum)[2 * QPT], int h0) {
 #pragma unroll
-                for (int j = 0; j < 2 * QPT; ++j) {
-                    const int wd = (h0 >> 1) + 2 * ((j >> 1) * BW_THREADS + (int)threadIdx.x) + (j & 1);
-                    const int s0 = 2 * wd;
-                    if (s0 >= c1 || s0 + 1 < c0 || s0 >= w) continue;
-                    const uint32_t v = dsum[j];
-                    if ((v & 0xFFFFu) < thq && (v >> 16) < thq) continue;   // (nearly every word)
-                    const uint32_t other = n_sparse > 0 ? acc[wd] : 0u;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
-                        const int slot = s0 + u;
-                        // (a doc that holds one of the other terms was scored by stage A)
-                        if (a != 0u && a >= thq && ((other >> (u << 4)) & 0xFFFFu) == 0u && slot >= c0 && slot < c1 && slot < w) {
-                            const int at = atomicAdd(&n_surv, 1);
-                            if (at < SURV_CAP) surv[at] = (uint16_t)slot;
-                        }
+                    for (int j = 0; j < 2 * QPT; ++j) dsum[j] = 0u;
+                    for (int i = 0; i < np; ++i) {
+                        uint32_t v[QPT];
+                        load_rows(v, i, h0);
+                        add_rows(dsum, v, i);
                     }
-                }
-            };
-            auto phase2 = [&](int ns) {
-                for (int base = 0; base < ns; base += BW_THREADS) {
-                    const int j = base + threadIdx.x;
-                    bool keep = j < ns;
-                    double score = 0.0;
-                    int32_t d = 0;
-                    if (keep) {
-                        d = (int32_t)(cursor + surv[j]);
-                        if (qc != -1 && doc_coll[d] != qc) keep = false;
-                        if (keep) {
-                            const double dl = (double)doclen[d];
-                            int tfv[8];
+                };
+                // ---- scan: the docs whose bound reaches the threshold ----
+                const uint32_t thq = (uint32_t)p_thq;
+                auto scan = [&](int c0, int c1, const uint32_t (&dsum)[2 * QPT], int h0) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                tfv[e] = 0;
-                                if (e < nt) {
-                                    const int64_t row = t_row[e];
-                                    if (row >= 0) tfv[e] = (int)dense_tf[row + d];
-                                }
+                    for (int j = 0; j < 2 * QPT; ++j) {
+                        const int s0 = h0 + 4 * ((j >> 1) * BW_THREADS + (int)threadIdx.x) + 2 * (j & 1);
+                        if (s0 >= c1 || s0 + 1 < c0 || s0 >= w) continue;
+                        const uint32_t v = dsum[j];
+                        if ((v & 0xFFFFu) < thq && (v >> 16) < thq) continue;   // (nearly every word)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t a = (v >> (u << 4)) & 0xFFFFu;
+                            const int slot = s0 + u;
+                            if (a != 0u && a >= thq && slot >= c0 && slot < c1 && slot < w) {
+                                const int at = atomicAdd(&n_surv, 1);
+                                if (at < SURV_CAP) surv[at] = (uint16_t)slot;
                             }
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (tfv[e] > 0)
-                                    score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tfv[e], dl, avgdl, k1, b));
                         }
                     }
-                    push(keep, score, (int64_t)d);
-                }
-            };
-            scan(0, w, dsum0, 0);
-#pragma unroll 1
-            for (int h0 = BW_SCAN; h0 < w; h0 += BW_SCAN) {
-                uint32_t dsum1[2 * QPT];
-                dense_sums(dsum1, h0);
-                scan(0, w, dsum1, h0);
-            }
-            __syncthreads();
-            BM_STAMP(13);
-            const int ns = n_surv;
-            BM_COUNT(17, ns);
-            BM_COUNT(18, (ns + BW_THREADS - 1) / BW_THREADS);
-            if (ns <= SURV_CAP) {
-                phase2(ns);
-            } else {   // (passes without a threshold) SURV_CAP slots at a time
-                for (int c0 = 0; c0 < w; c0 += SURV_CAP) {
-                    __syncthreads();
-                    if (threadIdx.x == 0) n_surv = 0;
-                    __syncthreads();
-                    {   // (the sums again: they are not kept across phase 2)
-                        const int h0 = c0 / BW_SCAN * BW_SCAN;
-                        uint32_t dsum1[2 * QPT];
-                        dense_sums(dsum1, h0);
-                        scan(c0, c0 + SURV_CAP, dsum1, h0);
+                };
+                auto phase2 = [&](int ns) {
+                    for (int base = 0; base < ns; base += BW_THREADS) {
+                        const int j = base + threadIdx.x;
+                        bool keep = j < ns;
+                        double score = 0.0;
+                        int32_t d = 0;
+                        if (keep) {
+                            d = (int32_t)(cursor + surv[j]);
+                            if (n_walked > 0) {   // (a doc that holds a walked term was scored by stage A)
+                                const uint32_t bit = (uint32_t)(d - g0);
+                                if ((bits[bit >> 5] >> (bit & 31)) & 1u) keep = false;
+                            }
+                            if (keep && qc != -1 && doc_coll[d] != qc) keep = false;
+                            if (keep) {
+                                const double dl = (double)doclen[d];
+                                int tfv[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    tfv[e] = 0;
+                                    if (e < nt) {
+                                        const int64_t row = t_row[e];
+                                        if (row >= 0) tfv[e] = (int)dense_tf[row + d];
+                                    }
+                                }
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    if (tfv[e] > 0)
+                                        score = __dadd_rn(score, bm25_contrib(t_idf[e], (double)tfv[e], dl, avgdl, k1, b));
+                            }
+                        }
+                        push(keep, score, (int64_t)d);
                     }
-                    __syncthreads();
-                    phase2(n_surv);
+                };
+                BM_COUNT(14, 1);
+                BM_COUNT(16, w);
+                // BW_SCAN docs per step; the rows of the first PF probed terms for the NEXT step are
+                // requested before this step's sums and scan (a step is otherwise one round trip long)
+                constexpr int PF = 4;
+                uint32_t nxt[PF][QPT];
+#pragma unroll
+                for (int i = 0; i < PF; ++i)
+                    if (i < np) load_rows(nxt[i], i, 0);
+#pragma unroll 1
+                for (int h0 = 0; h0 < w; h0 += BW_SCAN) {
+                    uint32_t cur[PF][QPT];
+#pragma unroll
+                    for (int i = 0; i < PF; ++i)
+#pragma unroll
+                        for (int j = 0; j < QPT; ++j) cur[i][j] = nxt[i][j];
+                    if (h0 + BW_SCAN < w) {
+#pragma unroll
+                        for (int i = 0; i < PF; ++i)
+                            if (i < np) load_rows(nxt[i], i, h0 + BW_SCAN);
+                    }
+                    uint32_t dsum[2 * QPT];
+#pragma unroll
+                    for (int j = 0; j < 2 * QPT; ++j) dsum[j] = 0u;
+#pragma unroll
+                    for (int i = 0; i < PF; ++i)
+                        if (i < np) add_rows(dsum, cur[i], i);
+                    for (int i = PF; i < np; ++i) {
+                        uint32_t v[QPT];
+                        load_rows(v, i, h0);
+                        add_rows(dsum, v, i);
+                    }
+                    scan(0, w, dsum, h0);
                 }
-            }
-            __syncthreads();
-            BM_STAMP(5);
-            if (b_cnt >= k && b_cnt - last_compact >= 64) {
-                BM_COUNT(15, 1);
-                tk.compact();
-                if (threadIdx.x == 0) {
-                    last_compact = b_cnt;
-                    if (S > 1 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+                __syncthreads();
+                BM_STAMP(13);
+                const int ns = n_surv;
+                BM_COUNT(17, ns);
+                BM_COUNT(18, (ns + BW_THREADS - 1) / BW_THREADS);
+                if (ns <= SURV_CAP) {
+                    phase2(ns);
+                } else {   // (passes without a threshold) SURV_CAP slots at a time
+                    for (int c0 = 0; c0 < w; c0 += SURV_CAP) {
+                        __syncthreads();
+                        if (threadIdx.x == 0) n_surv = 0;
+                        __syncthreads();
+                        {   // (the sums again: they are not kept across phase 2)
+                            const int h0 = c0 / BW_SCAN * BW_SCAN;
+                            uint32_t dsum[2 * QPT];
+                            dense_sums(dsum, h0);
+                            scan(c0, c0 + SURV_CAP, dsum, h0);
+                        }
+                        __syncthreads();
+                        phase2(n_surv);
+                    }
                 }
+                __syncthreads();
+                BM_STAMP(5);
+                if (b_cnt >= k && b_cnt - last_compact >= 64) {
+                    BM_COUNT(15, 1);
+                    tk.compact();
+                    if (threadIdx.x == 0) {
+                        last_compact = b_cnt;
+                        if (S > 1 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+                    }
+                }
+                if (threadIdx.x == 0 && S > 1 && gth) {
+                    const double g = dkey_inv(gth);
+                    if (g > th_glob) th_glob = g;
+                }
+                cursor = end;
+                prepare();
+                __syncthreads();
+                BM_STAMP(10);
             }
-            // the postings this pass consumed (those of docs below its end), then the next pass's needs
-            if ((int)threadIdx.x < nt && t_staged[threadIdx.x] > 0)
-                tr[threadIdx.x].cur += count_below(st_doc + tr[threadIdx.x].lds_off, t_staged[threadIdx.x], end);
-            cursor = end;
-            if (cursor < D1) prepare(cursor);
-            __syncthreads();
-            BM_STAMP(10);
         }
         const int n = tk.finish();
         if (S == 1) {
@@ -1711,7 +1710,12 @@ struct BmLayout {
 };
 static BmLayout bm_layout(int nq, int mt, int k) {
     BmLayout L;
-    L.cap = 2 * nq + BM_EXTRA_ITEMS;   // (a query with dense terms is at least two items: stage A, stage B)
+    static int extra = 0;
+    if (!extra) {
+        const char* ev = getenv("THR_BM25_ITEMS");   // item slots beyond two per query (A/B knob)
+        extra = ev && atoi(ev) >= 1024 ? atoi(ev) : BM_EXTRA_ITEMS;
+    }
+    L.cap = 2 * nq + extra;   // (a query with dense terms is at least two items: stage A, stage B)
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -1926,20 +1930,11 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #else
 #define BW_STAMP_ARG
 #endif
-#define THR_BM25_WINDOW_LAUNCH(W)                                                                        \
-    hipLaunchKernelGGL((bm25_window_kernel<512, 4096, W, 1024>), dim3(wgrid), dim3(512), 0, st, rowptr,  \
-                       post_doc, post_tf, doclen, idf, post_imp, dslot, dense_imp, dense_tf, dense_stride, \
-                       avgdl, k1, b, n_docs, id_base, max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S,  \
-                       q_SA, q_pmask, q_terms, items, sweep_items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores, \
-                       out_ids, out_counts BW_STAMP_ARG)
-        static int wdocs = 0;
-        if (!wdocs) {
-            const char* ev = getenv("THR_BM25_WINDOW");   // docs per window pass, in thousands (A/B knob)
-            wdocs = ev && atoi(ev) == 8 ? 8192 : BW_DOCS0;
-        }
-        if (wdocs == 8192) THR_BM25_WINDOW_LAUNCH(8192);
-        else THR_BM25_WINDOW_LAUNCH(BW_DOCS0);
-#undef THR_BM25_WINDOW_LAUNCH
+        hipLaunchKernelGGL((bm25_window_kernel<512, 8192, 1024>), dim3(wgrid), dim3(512), 0, st, rowptr, post_doc,
+                           doclen, idf, dslot, dense_imp, dense_tf, dense_stride, avgdl, k1, b, n_docs, id_base,
+                           max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S, q_SA, q_pmask, q_terms, items,
+                           sweep_items, ipos, theta, slice_s, slice_id, slice_cnt, out_scores, out_ids,
+                           out_counts BW_STAMP_ARG);
         if ((rc = launch_status())) return rc;
     }
     THR_BM25_LAUNCH_SHAPE(false);
