@@ -16,4 +16,8 @@ python3 bench.py --dim 1024 --config dense --no-extras --no-cpu-baseline > $D/be
 python3 bench.py --lexical-mix no-stopwords --no-cpu-baseline > $D/bench_no_stopwords.json.log 2>&1
 bash scripts/pmc_passes.sh $D/pmc_scan 2048 > $D/pmc_scan.log 2>&1
 python3 scripts/pmc_counters.py $D/pmc_scan dense_scan_f16qs $D/scan_f16qs_counters.json "768, 1" > $D/pmc_fold.log 2>&1
+# BM25 alone: three query mixes, kernel stats and counters of its three kernels on 2048 df-proportional queries
+python3 scripts/bench_bm25.py > $D/bench_bm25.json 2> $D/bench_bm25.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_bm25 -o bm25 -- python3 scripts/pmc_bm25.py 4 50 dffull > $D/prof_bm25.log 2>&1
+bash scripts/pmc_bm25.sh $D/pmc_bm25 dffull > $D/pmc_bm25.log 2>&1
 ls $D

@@ -322,6 +322,31 @@ def test_bm25_small_block_shape_in_a_subprocess():
     assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
+@pytest.mark.parametrize("knobs", ["THR_BM25_DENSE=0", "THR_BM25_WALK_DIV=8 THR_BM25_ITEMS=1024",
+                                   "THR_BM25_SHAPE=small THR_BM25_DENSE_SHARE=0.05"])
+def test_bm25_dense_row_knobs_in_a_subprocess(knobs):
+    """The A/B knobs around the dense-term rows change the cost, never the result: without the rows
+    in the kernels (THR_BM25_DENSE=0), with nearly every row term walked and the fewest work items
+    (coarse slices, the sweep filter deciding on other thresholds), with the small block shape and
+    another share -- the BM25 parity tests run again under each (read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if env.get("THR_BM25_KNOB_RUN"):
+        pytest.skip("already inside a knob run")
+    env["THR_BM25_KNOB_RUN"] = "1"
+    for kv in knobs.split():
+        name, value = kv.split("=")
+        env[name] = value
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                          "test_bm25_matches_oracle or test_bm25_pruning_and_filters_stay_exact or "
+                          "test_bm25_dense_term_rows_equal_the_posting_walk"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "3 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
 def test_bm25_pruning_and_filters_stay_exact(T):
     """The WAND-style pruning (term / block score bounds), the conjunctive mode, the collection
     filter and an out-of-vocabulary term id: each equals the oracle bit for bit -- also on
