@@ -322,13 +322,14 @@ def test_bm25_small_block_shape_in_a_subprocess():
     assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
-@pytest.mark.parametrize("knobs", ["THR_BM25_DENSE=0", "THR_BM25_WALK_DIV=8 THR_BM25_ITEMS=1024",
-                                   "THR_BM25_SHAPE=small THR_BM25_DENSE_SHARE=0.05"])
+@pytest.mark.parametrize("knobs", ["THR_BM25_DENSE=0", "THR_BM25_WALK_DIV=8 THR_BM25_ITEMS=1024 THR_BM25_FUSE_DIV=0",
+                                   "THR_BM25_SHAPE=small THR_BM25_DENSE_SHARE=0.05 THR_BM25_FUSE_DIV=1000000"])
 def test_bm25_dense_row_knobs_in_a_subprocess(knobs):
     """The A/B knobs around the dense-term rows change the cost, never the result: without the rows
     in the kernels (THR_BM25_DENSE=0), with nearly every row term walked and the fewest work items
-    (coarse slices, the sweep filter deciding on other thresholds), with the small block shape and
-    another share -- the BM25 parity tests run again under each (read once per process)."""
+    (coarse slices, the sweep filter deciding on other thresholds) and stage A always a launch of
+    its own, with the small block shape, another share and stage A always fused with the ordinary
+    items' launch -- the BM25 parity tests run again under each (read once per process)."""
     import os
     import subprocess
     import sys

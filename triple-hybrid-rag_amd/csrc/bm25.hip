@@ -461,7 +461,8 @@ constexpr int BM_NSTAMP = 20;   // 0-13 phases (cycles), 14-19 counters
 #define BM_COUNT(i, v)
 #endif
 
-template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP, bool DP>
+// DPM: 0 = ordinary queries only, 1 = stage-A slices only, 2 = both kinds in one launch (decided per item)
+template <int BM_THREADS, int BM_STAGE, int BM_WINDOW, int BM_CAP, int DPM>
 __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
     const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp,
     const int32_t* __restrict__ dense_slot, const uint16_t* __restrict__ dense_tf, int64_t dense_stride,
     double avgdl, double k1, double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
-    const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
+    const int32_t* __restrict__ query_coll, int n_queries, int fuse_div, int32_t* __restrict__ ctl,
     const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
     const int32_t* __restrict__ q_pmask,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items,
@@ -523,20 +524,28 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     uint32_t* mask = scratch;
 
     const int n_items = ctl[0];
-    if (DP && ctl[3] == 0) return;   // no query of the batch holds a dense term
+    {   // Which launches work is decided on the device (no host round trip): when at least 1/fuse_div of
+        // the batch's queries hold dense terms, ONE launch (DPM 2) takes the ordinary items and the
+        // stage-A slices together -- two half-empty persistent grids, each with its own tail, cost
+        // more than the row probes' registers cost the ordinary items (256 / 2048 survey queries:
+        // 0.85 -> 0.60 / 1.83 -> 1.55 ms; a batch without dense terms: 0.49 -> 0.55 ms, hence the switch).
+        const int nd = ctl[3];
+        const bool fuse = fuse_div > 0 && nd > 0 && (long long)nd * fuse_div >= n_queries;
+        if (DPM == 2 ? !fuse : DPM == 1 ? (fuse || nd == 0) : fuse) return;
+    }
     BlockTopK<BM_CAP, BM_THREADS> tk;
     for (;;) {
         __syncthreads();   // the previous item's LDS state is no longer read
-        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[DP ? 4 : 1], 1);
+        if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[DPM == 1 ? 4 : 1], 1);
         __syncthreads();
         const int item = cur_item;
         if (item >= n_items) break;   // (uniform: every workgroup of the grid ends here)
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
-        {   // a query with dense terms: its first q_SA slices are the DP build's, the rest bm25_window_kernel's
-            const int SA = q_SA[q];
-            if (DP ? !(SA >= 0 && sl < SA) : SA >= 0) continue;
-        }
+        // a query with dense terms: its first q_SA slices are stage A's (DP), the rest bm25_window_kernel's
+        const int SA_ = q_SA[q];
+        if (DPM == 0 ? SA_ >= 0 : DPM == 1 ? !(SA_ >= 0 && sl < SA_) : (SA_ >= 0 && sl >= SA_)) continue;
+        const bool DP = DPM == 1 || (DPM == 2 && SA_ >= 0);
         const int S = q_S[q];
         const int nt = q_nt[q];
         const int qc = query_coll ? query_coll[q] : -1;   // -1: no collection filter
@@ -1861,7 +1870,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
-    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1, walk_div = 64;
+    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1, walk_div = 64, fuse_div = 8;
     if (small < 0) {
         const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
         use_imp = !(ei && ei[0] == '0');
@@ -1869,6 +1878,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         use_dense = !(ei && ei[0] == '0');
         ei = getenv("THR_BM25_WALK_DIV");             // a term with rows may be walked when held by < 1/this of the docs
         if (ei && atoi(ei) > 0) walk_div = atoi(ei);
+        ei = getenv("THR_BM25_FUSE_DIV");             // one launch for ordinary items + stage A from 1/this of the queries (0: never)
+        if (ei && atoi(ei) >= 0) fuse_div = atoi(ei);
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : (ev && ev[0] == 'h') ? 2 : 0;   // s(mall) / h(uge)
         ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
@@ -1892,7 +1903,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #ifdef BM_STAMPS
     unsigned long long* d_stamps = (unsigned long long*)(ws + L.off_stamps);
     if (grid > 4096) grid = 4096;
-#define BM_STAMP_ARG(DP) , d_stamps + (DP ? 2 : 0) * (size_t)4096 * (BM_NSTAMP + 1)
+#define BM_STAMP_ARG(DP) , d_stamps + (DP == 1 ? 2 : 0) * (size_t)4096 * (BM_NSTAMP + 1)
 #else
 #define BM_STAMP_ARG(DP)
 #endif
@@ -1906,7 +1917,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
                        (term_ub && use_imp) ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
                        avgdl, k1, b,                                                                \
-                       id_base, max_terms, k, conjunctive, doc_coll, query_coll, ctl, q_nt, q_S,    \
+                       id_base, max_terms, k, conjunctive, doc_coll, query_coll, n_queries,         \
+                       dslot ? fuse_div : 0, ctl, q_nt, q_S,                                        \
                        q_SA, q_pmask, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt,    \
                        out_scores, out_ids, out_counts BM_STAMP_ARG(DP))
 #define THR_BM25_LAUNCH_SHAPE(DP)                                                                     \
@@ -1919,7 +1931,10 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         // queries with dense terms: stage A (their other terms' postings, the dense rows probed), then
         // stage B (doc-window sweeps, skipped where stage A's threshold rules them out).  Every kernel
         // walks the one item list and takes the items that are its own.
-        THR_BM25_LAUNCH_SHAPE(true);
+        // (of these two and the ordinary launch further down, the kernels themselves pick who works:
+        // the fused one when many of the batch's queries hold dense terms, else the two others)
+        THR_BM25_LAUNCH_SHAPE(2);
+        THR_BM25_LAUNCH_SHAPE(1);
         if ((rc = launch_status())) return rc;
         hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, st, ctl, items,
                            q_SA, q_dub, theta, slice_cnt, sweep_items);
@@ -1937,7 +1952,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                            out_counts BW_STAMP_ARG);
         if ((rc = launch_status())) return rc;
     }
-    THR_BM25_LAUNCH_SHAPE(false);
+    THR_BM25_LAUNCH_SHAPE(0);
 #ifdef BM_STAMPS
     {
         static const char* names[BM_NSTAMP] = {"item set-up", "init", "quotas", "staging", "edges/prefix", "phase 2 (+ chunk reset)",
