@@ -9,7 +9,9 @@ run sqA "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_IN
 run sqB "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"
 run sqC "SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_IFETCH SQ_INSTS_BRANCH"
 run fetch "FETCH_SIZE"
-# three kernels since ABI 7: the posting walk of ordinary queries, stage A (dense rows probed), stage B (doc windows)
-python3 scripts/pmc_counters.py $D bm25_topk_kernel $D/counters_walk.json "false>"
-python3 scripts/pmc_counters.py $D bm25_topk_kernel $D/counters_stage_a.json "true>"
+# the kernels since ABI 7: the posting walk -- ordinary items and stage-A slices in ONE launch (template
+# argument 2) when an eighth of the batch holds dense terms, else a launch each (0 / 1) -- and stage B
+python3 scripts/pmc_counters.py $D bm25_topk_kernel $D/counters_walk_fused.json ", 2>"
+python3 scripts/pmc_counters.py $D bm25_topk_kernel $D/counters_walk.json ", 0>"
+python3 scripts/pmc_counters.py $D bm25_topk_kernel $D/counters_stage_a.json ", 1>"
 python3 scripts/pmc_counters.py $D bm25_window_kernel $D/counters_stage_b.json
