@@ -434,8 +434,20 @@ def test_lazy_rows_and_the_layout_rule():
     assert calls == []                       # nothing is read back before the rows are looked at
     assert [r["child_id"] for r in rows] == ["a", "b"] and len(rows) == 2 and rows and calls == [1]
     assert rows[1]["child_id"] == "b" and rows == [{"child_id": "a"}, {"child_id": "b"}] and calls == [1]
-    broken = LazyRows(lambda: 1 / 0)         # a failing deferred part is an empty channel
-    assert list(broken) == [] and not broken
+    assert rows + [1] == [{"child_id": "a"}, {"child_id": "b"}, 1] and {"child_id": "b"} in rows
+    assert list(reversed(rows))[0]["child_id"] == "b" and not isinstance(rows, list)
+    import json
+    assert json.loads(json.dumps(rows.materialize())) == [{"child_id": "a"}, {"child_id": "b"}]
+    # a failing deferred part RAISES at the first look and at every later one (the reference's
+    # _lexical_search has no try/except, retrieval.py:273-292): a GPU fault is never an empty channel
+    boom = []
+    broken = LazyRows(lambda: boom.append(1) or 1 / 0)
+    for _ in range(2):
+        with pytest.raises(ZeroDivisionError):
+            list(broken)
+        with pytest.raises(ZeroDivisionError):
+            len(broken)
+    assert boom == [1]                       # the fetch itself ran once
     # one GPU: no split; the 1M-doc headline corpus: 2 shards x N/2 replicas; 10M docs: N shards
     assert [auto_doc_shards(w, 1_000_000) for w in (1, 2, 4, 8)] == [1, 2, 2, 2]
     assert [auto_doc_shards(w, 10_000_000) for w in (1, 2, 4, 8)] == [1, 2, 4, 8]

@@ -75,6 +75,22 @@ def stale() -> bool:
     return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
+import contextlib
+import fcntl
+
+
+@contextlib.contextmanager
+def _build_lock():
+    """Exclusive lock on build/ for the link step (the objects are each renamed into place)."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into one shared library.  hipcc cross-compiles
     without a GPU, so this also runs in the build container."""
@@ -87,20 +103,31 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     todo = [s for s in sources() if force or _obj_stale(s)]
 
     def compile_one(src):
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", _obj(src)]
+        # to a name of this process's own, then renamed into place: several processes that find
+        # the tree stale at once (torchrun ranks, the knob tests' subprocesses) never link a
+        # half-written object of another
+        tmp = f"{_obj(src)}.tmp{os.getpid()}"
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        os.replace(tmp, _obj(src))
         for old in glob.glob(_obj(src) + ".*"):
-            os.remove(old)
+            if ".tmp" not in os.path.basename(old):
+                try:
+                    os.remove(old)
+                except FileNotFoundError:
+                    pass
         open(_obj(src) + "." + _stamp(), "w").close()
 
     with ThreadPoolExecutor(max_workers=min(len(todo) or 1, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
+    tmp_lib = f"{LIB_PATH}.tmp{os.getpid()}"
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in sources()] + \
-        ["-o", LIB_PATH + ".tmp"]
+        ["-o", tmp_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with _build_lock():
+        subprocess.check_call(cmd)
+        os.replace(tmp_lib, LIB_PATH)
     return LIB_PATH

@@ -17,6 +17,7 @@ unspecified; the reference ranks graph hits by that order, Appendix A.7).
 """
 from __future__ import annotations
 
+import collections.abc
 import re
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence
@@ -90,42 +91,61 @@ class _Reply:
         return self
 
 
-class LazyRows(list):
+class LazyRows(collections.abc.Sequence):
     """Rows of an RPC whose kernels are in flight: the read-back happens when the rows are first
     looked at, so the caller can issue its next RPC in the meantime.  A failure of the deferred
-    part degrades to an empty channel, as a failing RPC does in the reference (retrieval.py:291)."""
+    part (the read-back is where an asynchronous HIP error of the lexical kernels surfaces) RAISES
+    at that first look and again on every later one -- the reference's ``_lexical_search`` has no
+    try/except either (retrieval.py:273-292: only the graph channel swallows errors), so a failing
+    lexical RPC propagates out of ``retrieve()``; a GPU fault never becomes an empty channel.
+    Not a ``list`` subclass: every consumer goes through the Sequence protocol, so nothing can
+    read an unfilled list storage behind the fetch (``json.dumps(rows.materialize())`` for C-level
+    consumers that insist on a real list)."""
+
+    __slots__ = ("_fetch", "_rows", "_error")
 
     def __init__(self, fetch):
-        super().__init__()
         self._fetch = fetch
+        self._rows = None
+        self._error = None
 
-    def _ready(self):
-        fetch, self._fetch = self._fetch, None
-        if fetch is not None:
+    def materialize(self) -> list:
+        """The rows as a plain list (fetched once; a failed fetch re-raises its exception)."""
+        if self._error is not None:
+            raise self._error
+        if self._rows is None:
+            fetch, self._fetch = self._fetch, None
             try:
-                super().extend(fetch())
-            except Exception as exc:  # noqa: BLE001
-                import logging
-                logging.getLogger(__name__).warning("deferred RPC failed: %s", exc)
+                self._rows = list(fetch())
+            except BaseException as exc:
+                self._error = exc
+                raise
+        return self._rows
+
+    _ready = materialize
 
     def __iter__(self):
-        self._ready()
-        return super().__iter__()
+        return iter(self.materialize())
 
     def __len__(self):
-        self._ready()
-        return super().__len__()
-
-    def __bool__(self):
-        return len(self) > 0
+        return len(self.materialize())
 
     def __getitem__(self, i):
-        self._ready()
-        return super().__getitem__(i)
+        return self.materialize()[i]
 
     def __eq__(self, other):
-        self._ready()
-        return list(self) == other
+        if isinstance(other, LazyRows):
+            other = other.materialize()
+        return self.materialize() == other
+
+    def __add__(self, other):
+        return self.materialize() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.materialize()
+
+    def __repr__(self):
+        return f"LazyRows({'pending' if self._rows is None and self._error is None else self._rows!r})"
 
     __hash__ = None
 
@@ -339,8 +359,11 @@ class GpuIndexClient:
         the retriever issues its semantic RPC in between, and the two channels overlap."""
         pending = getattr(self, "_pending_lex", None)
         if pending is not None:     # a deferred call still owns the index's lexical workspace:
-            pending._ready()        # read it back before the kernels of this one are enqueued
             self._pending_lex = None
+            try:
+                pending.materialize()   # read it back before the kernels of this one are enqueued
+            except Exception:           # (its own caller sees that failure when it looks at the rows)
+                pass
         terms: List[int] = []
         unknown = False
         for tok in tokenize(query):

@@ -63,6 +63,7 @@ class GpuIndex:
         self._ws_rescue: Optional[torch.Tensor] = None
         self._ws_lex: Optional[torch.Tensor] = None
         self._ws_graph: Optional[torch.Tensor] = None
+        self._lex_done = None   # event: the last bm25_search's kernels have left the lexical workspace
 
     # ------------------------------------------------------------ builders
     def _t(self, a, dtype):
@@ -278,8 +279,22 @@ class GpuIndex:
         qt = self._t(query_terms, torch.int32)
         dc, qc = self._qcoll(collections, qt.shape[0])
         need = N.bm25_workspace_bytes(qt.shape[0], qt.shape[1], k)
+        # ONE lexical workspace per index, used from whichever stream the caller is on (the main
+        # one, or the side stream of side_channels / GpuIndexClient's deferred RPC): the stream of
+        # this call waits for the previous call's kernels before its memset touches the workspace
+        cur = torch.cuda.current_stream(self.device)
+        if self._lex_done is not None:
+            cur.wait_event(self._lex_done)
         if self._ws_lex is None or self._ws_lex.numel() < need:   # kept: no allocation per search
             self._ws_lex = torch.empty(need, dtype=torch.uint8, device=self.device)
+        try:
+            return self._bm25_call(L, qt, k, dc, qc, conjunctive, prune, dense_rows)
+        finally:
+            if self._lex_done is None:
+                self._lex_done = torch.cuda.Event()
+            self._lex_done.record(cur)
+
+    def _bm25_call(self, L, qt, k, dc, qc, conjunctive, prune, dense_rows):
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
                            L["avgdl"], qt, k, self.doc_base, L["k1"], L["b"],
                            bounds=L["bounds"] if prune else None, conjunctive=conjunctive,
