@@ -133,85 +133,100 @@ def main():
     need_tok = "triple_rerank" in run_cfgs
 
     # ---- inputs (deterministic, identical for every world size) ----
+    import types
     doc_shards = args.doc_shards
     if not doc_shards:   # auto: shard only as far as the scan still dominates a shard's step
         doc_shards = auto_doc_shards(world, args.docs, args.min_shard_docs)
-    shard, replica, _ = layout_2d(rank, world, doc_shards)
-    n_replicas = world // doc_shards
-    group = None
-    if world > 1 and n_replicas > 1:
-        group = replica_groups(world, doc_shards)[replica]
-    lo, hi = shard_range(args.docs, shard, doc_shards)
-    n_local = hi - lo
     nq = args.queries
-    t0 = time.time()
-    docs = synth.dense_rows(lo, n_local, args.dim)
-    queries = synth.dense_queries(nq * n_replicas, args.dim, args.docs)
-    queries = np.ascontiguousarray(queries[replica::n_replicas])   # this replica's batch
-    index = T.GpuIndex(doc_base=lo).set_dense(docs, shortlist=args.shortlist)
-    qt = seeds = qtok = None
-    csr = graph = None
-    if need_lex:
-        v = synth.vocab_size(args.docs)
-        d_, t_, f_ = synth.lexical_rows(lo, n_local, args.docs)
-        csr = synth.build_lexical_csr(d_, t_, f_, n_local, v)
-        df = torch.from_numpy(csr.df_local.copy())
-        sdl = torch.tensor([csr.sum_dl_local], dtype=torch.float64)
-        if world > 1:   # global statistics: every shard scores as the whole corpus would
-            dev_ = "cpu" if rehearsal else "cuda"
-            df, sdl = df.to(dev_), sdl.to(dev_)
-            dist.all_reduce(df)
-            dist.all_reduce(sdl)
-            df, sdl = df.cpu(), sdl.cpu()
-        df = df.numpy()
-        idf = np.log(1.0 + (args.docs - df.astype(np.float64) + 0.5) / (df.astype(np.float64) + 0.5))
-        index.set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, float(sdl.item()) / args.docs)
-        dfq = df.copy()
-        dfq[dfq > 0.01 * args.docs] = 0          # the "no-stopwords" mix: no term held by > 1 % of the docs
-        qt_alt = {"survey": synth.lexical_queries(nq * n_replicas, df, 4)[replica::n_replicas],
-                  "no-stopwords": synth.lexical_queries(nq * n_replicas, dfq, 4)[replica::n_replicas]}
-        qt = qt_alt[args.lexical_mix]
-    if need_graph:
-        graph = synth.build_graph(args.docs, lo, hi)
-        index.set_graph(graph.ent_rowptr, graph.ent_col, graph.men_rowptr, graph.men_chunk, graph.men_conf)
-        seeds = synth.graph_queries(nq * n_replicas, args.docs, 3)[replica::n_replicas]
-    if need_tok:
-        n_tok = min(n_local, args.token_docs) if args.token_docs else n_local
-        index.set_tokens(synth.device_tokens(lo, n_tok))
-        g = torch.Generator(device="cuda")
-        g.manual_seed(4321 + 3)
-        qtok = torch.nn.functional.normalize(torch.randn((nq * n_replicas, 32, 128), generator=g, device="cuda"),
-                                             dim=2).to(torch.float16)[replica::n_replicas].contiguous()
-    gen_s = time.time() - t0
-    index.reserve(nq, 100)   # workspaces are part of the resident index, not of a step
-    sharded = ShardedIndex(index, group=group)
-    # The step starts where the reference's embed_query() starts its post-processing
-    # (rag2/embedder.py:226-241): the embedding model's 4096-d vectors, resident in HBM.  Their
-    # first ``dim`` components are the synthetic query directions at an arbitrary scale, the rest
-    # is noise that the Matryoshka truncation drops; thr_embed_postproc (truncate + float32
-    # L2-normalise) is the first kernel of every timed step.
-    raw = np.empty((nq, 4096), dtype=np.float32)
-    raw[:, :args.dim] = queries * np.float32(3.7)
-    raw[:, args.dim:] = np.random.Generator(np.random.PCG64([4321, 9, replica])).standard_normal(
-        (nq, 4096 - args.dim), dtype=np.float32)
-    raw_pinned = torch.from_numpy(raw).pin_memory()
-    raw_dev = raw_pinned.cuda()
-    qd = T._native.embed_postproc(raw_dev, args.dim)   # (the query vectors the extras below use)
-    qtd = torch.from_numpy(np.ascontiguousarray(qt)).cuda() if qt is not None else None
-    sd = torch.from_numpy(np.ascontiguousarray(seeds)).cuda() if seeds is not None else None
-    torch.cuda.synchronize()
 
-    def step_fn(cfg):
+    def build(doc_shards):
+        """This rank's resident state for a layout of ``doc_shards`` document shards x
+        world / doc_shards query replicas: its shard's index, its replica's query batch."""
+        B = types.SimpleNamespace(doc_shards=doc_shards, n_replicas=world // doc_shards)
+        B.shard, B.replica, _ = layout_2d(rank, world, doc_shards)
+        n_replicas, replica = B.n_replicas, B.replica
+        B.group = None
+        if world > 1 and n_replicas > 1:
+            B.group = replica_groups(world, doc_shards)[replica]
+        lo, hi = shard_range(args.docs, B.shard, doc_shards)
+        B.lo, B.hi, B.n_local = lo, hi, hi - lo
+        t0 = time.time()
+        B.docs = synth.dense_rows(lo, B.n_local, args.dim)
+        queries = synth.dense_queries(nq * n_replicas, args.dim, args.docs)
+        B.queries = np.ascontiguousarray(queries[replica::n_replicas])   # this replica's batch
+        B.index = T.GpuIndex(doc_base=lo).set_dense(B.docs, shortlist=args.shortlist)
+        B.qt = B.seeds = B.qtok = B.csr = B.graph = B.qt_alt = B.idf = B.avgdl = None
+        if need_lex:
+            v = synth.vocab_size(args.docs)
+            d_, t_, f_ = synth.lexical_rows(lo, B.n_local, args.docs)
+            B.csr = synth.build_lexical_csr(d_, t_, f_, B.n_local, v)
+            df = torch.from_numpy(B.csr.df_local.copy())
+            sdl = torch.tensor([B.csr.sum_dl_local], dtype=torch.float64)
+            if doc_shards > 1:   # global statistics: every shard scores as the whole corpus would
+                dev_ = "cpu" if rehearsal else "cuda"   # (summed over the shards of ONE replica: its group)
+                df, sdl = df.to(dev_), sdl.to(dev_)
+                dist.all_reduce(df, group=B.group)
+                dist.all_reduce(sdl, group=B.group)
+                df, sdl = df.cpu(), sdl.cpu()
+            df = df.numpy()
+            B.idf = np.log(1.0 + (args.docs - df.astype(np.float64) + 0.5) / (df.astype(np.float64) + 0.5))
+            B.avgdl = float(sdl.item()) / args.docs
+            B.index.set_lexical(B.csr.rowptr, B.csr.post_doc, B.csr.post_tf, B.csr.doclen, B.idf, B.avgdl)
+            dfq = df.copy()
+            dfq[dfq > 0.01 * args.docs] = 0          # the "no-stopwords" mix: no term held by > 1 % of the docs
+            B.qt_alt = {"survey": synth.lexical_queries(nq * n_replicas, df, 4)[replica::n_replicas],
+                        "no-stopwords": synth.lexical_queries(nq * n_replicas, dfq, 4)[replica::n_replicas]}
+            B.qt = B.qt_alt[args.lexical_mix]
+        if need_graph:
+            B.graph = synth.build_graph(args.docs, lo, hi)
+            B.index.set_graph(B.graph.ent_rowptr, B.graph.ent_col, B.graph.men_rowptr, B.graph.men_chunk,
+                              B.graph.men_conf)
+            B.seeds = synth.graph_queries(nq * n_replicas, args.docs, 3)[replica::n_replicas]
+        if need_tok:
+            n_tok = min(B.n_local, args.token_docs) if args.token_docs else B.n_local
+            B.index.set_tokens(synth.device_tokens(lo, n_tok))
+            g = torch.Generator(device="cuda")
+            g.manual_seed(4321 + 3)
+            B.qtok = torch.nn.functional.normalize(torch.randn((nq * n_replicas, 32, 128), generator=g, device="cuda"),
+                                                   dim=2).to(torch.float16)[replica::n_replicas].contiguous()
+        B.gen_s = time.time() - t0
+        B.index.reserve(nq, 100)   # workspaces are part of the resident index, not of a step
+        B.sharded = ShardedIndex(B.index, group=B.group)
+        # The step starts where the reference's embed_query() starts its post-processing
+        # (rag2/embedder.py:226-241): the embedding model's 4096-d vectors, resident in HBM.  Their
+        # first ``dim`` components are the synthetic query directions at an arbitrary scale, the rest
+        # is noise that the Matryoshka truncation drops; thr_embed_postproc (truncate + float32
+        # L2-normalise) is the first kernel of every timed step.
+        B.raw = np.empty((nq, 4096), dtype=np.float32)
+        B.raw[:, :args.dim] = B.queries * np.float32(3.7)
+        B.raw[:, args.dim:] = np.random.Generator(np.random.PCG64([4321, 9, replica])).standard_normal(
+            (nq, 4096 - args.dim), dtype=np.float32)
+        B.raw_pinned = torch.from_numpy(B.raw).pin_memory()
+        B.raw_dev = B.raw_pinned.cuda()
+        B.qd = T._native.embed_postproc(B.raw_dev, args.dim)   # (the query vectors the extras below use)
+        B.qtd = torch.from_numpy(np.ascontiguousarray(B.qt)).cuda() if B.qt is not None else None
+        B.sd = torch.from_numpy(np.ascontiguousarray(B.seeds)).cuda() if B.seeds is not None else None
+        torch.cuda.synchronize()
+        return B
+
+    B = build(doc_shards)
+    # (the names the rest of this file uses)
+    n_replicas, group, n_local = B.n_replicas, B.group, B.n_local
+    docs, queries, index, csr, graph = B.docs, B.queries, B.index, B.csr, B.graph
+    qt, seeds, qtok, qt_alt, idf = B.qt, B.seeds, B.qtok, B.qt_alt, B.idf
+    raw, raw_pinned, raw_dev, qd, qtd, sd, gen_s = B.raw, B.raw_pinned, B.raw_dev, B.qd, B.qtd, B.sd, B.gen_s
+
+    def step_fn(cfg, B=B):
         kw = {}
         if cfg != "dense":
-            kw["query_terms"] = qtd
+            kw["query_terms"] = B.qtd
         if cfg.startswith("triple"):
-            kw["query_seeds"] = sd
+            kw["query_seeds"] = B.sd
         if cfg == "triple_rerank":
-            kw.update(qtok=qtok, rerank_top_k=100)
+            kw.update(qtok=B.qtok, rerank_top_k=100)
         w = {"lexical": 0.7, "semantic": 0.8} if cfg == "dense_bm25" else None   # configs[2]: RRF(0.8/0.7)
-        return lambda: sharded.retrieve_batch(T._native.embed_postproc(raw_dev, args.dim), top_k=args.top_k,
-                                              weights=w, **kw)
+        return lambda: B.sharded.retrieve_batch(T._native.embed_postproc(B.raw_dev, args.dim), top_k=args.top_k,
+                                                weights=w, **kw)
 
     def barrier():
         if world > 1:

@@ -1200,6 +1200,145 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
                 assert got[a] == exp[a]
 
 
+def _dropin_calls(client, n, d):
+    """What a user of the reference does with its retriever, over ``client``: retrieve() with a
+    graph-asking plan and a collection filter, the agent tool with nothing injected (tenant
+    discovery, default embedder / planner, MaxSim rerank), a refusal -- as JSON-able data."""
+    import asyncio
+    from triple_hybrid_rag_amd import backend, synth
+    from triple_hybrid_rag_amd.config import SETTINGS
+    from triple_hybrid_rag_amd.rag2.query_planner import QueryPlan
+    from triple_hybrid_rag_amd.rag2.retrieval import RAG2Retriever
+    from triple_hybrid_rag_amd.tools import crm_knowledge as crm
+    saved = dict(SETTINGS.__dict__)
+    q = synth.dense_queries(6, d, n)
+
+    class Emb:
+        def embed_query(self, text):
+            return q[sum(map(ord, text)) % 6].tolist()
+
+    class Planner:
+        async def plan_async(self, query, collection=None):
+            return QueryPlan(original_query=query, keywords=query.split(), semantic_query_text=query,
+                             requires_graph=True, cypher_query="MATCH (e) RETURN e")
+
+    out = {"retrieve": [], "tool": []}
+    try:
+        backend.set_default_client(client)
+        SETTINGS.rag2_enabled = SETTINGS.rag2_rerank_enabled = SETTINGS.rag2_graph_enabled = True
+        SETTINGS.rag2_embed_dim_store = d
+        SETTINGS.rag2_safety_threshold = SETTINGS.rag2_denoise_alpha = 0.0
+        loop = asyncio.new_event_loop()
+        for text, coll, rerank in (("t100 t2000 t77", None, False), ("t5 t9 entity12", "faq", False),
+                                   ("t3 t4000 t17 t2", None, True), ("entity3 t11", "pricing", True)):
+            r = RAG2Retriever(org_id="org-7", embedder=Emb(), query_planner=Planner(), graph_enabled=True)
+            r._supabase = client
+            res = loop.run_until_complete(r.retrieve(text, collection=coll, top_k=8, skip_rerank=not rerank))
+            out["retrieve"].append([[c.child_id, c.lexical_rank, c.semantic_rank, c.graph_rank, c.rrf_score,
+                                     c.rerank_score, c.parent_text] for c in res.contexts])
+        loop.close()
+        for text, cat in (("t100 t2000 t77", None), ("t100 t2000 t77", "faq")):
+            t = crm.search_knowledge_base(text, cat, 5)
+            t.pop("timings_ms", None)
+            out["tool"].append(t)
+        SETTINGS.rag2_safety_threshold = 10.0
+        out["tool"].append(crm.search_knowledge_base("t100 t2000 t77", None, 5))
+    finally:
+        SETTINGS.__dict__.update(saved)
+        backend.set_default_client(None)
+    return out
+
+
+class _TokEmb:
+    def embed_query_tokens(self, query):
+        from triple_hybrid_rag_amd import synth
+        return synth.query_tokens(4, 32, 64)[sum(map(ord, query)) % 4]
+
+
+def _dropin_store(n):
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.backend import CorpusStore
+    store = CorpusStore.synthetic(n, vocab_size=synth.vocab_size(n),
+                                  n_entities=synth.build_graph(n).ent_rowptr.shape[0] - 1)
+    store.collections = ["faq" if i % 5 == 0 else "pricing" for i in range(n)]
+    return store
+
+
+def _sharded_client_worker(rank, world, port, n, d, out_dir):
+    import json
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import triple_hybrid_rag_amd as T
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import shard_range
+    from triple_hybrid_rag_amd.sharded_client import ShardedIndexClient, ShardWorker
+    torch.cuda.set_device(0)
+    lo, hi = shard_range(n, rank, world)
+    doc, term, tf = synth.lexical_rows(lo, hi - lo, n)
+    csr = synth.build_lexical_csr(doc, term, tf, hi - lo, synth.vocab_size(n))
+    df, sum_dl = synth.lexical_global_stats(n)   # the whole corpus' statistics on every shard
+    g = synth.build_graph(n, lo, hi)
+    idx = (T.GpuIndex(doc_base=lo).set_dense(synth.dense_rows(lo, hi - lo, d))
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, O.bm25_idf(n, df), sum_dl / n)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf)
+           .set_tokens(synth.doc_tokens(lo, hi - lo, 32, 64))
+           .set_collections(np.array([0 if i % 5 == 0 else 1 for i in range(lo, hi)], dtype=np.int32)))
+    names = ["faq", "pricing"]
+    if rank != 0:
+        served = ShardWorker(idx, collection_names=names).serve()
+        with open(os.path.join(out_dir, f"served{rank}.json"), "w") as f:
+            json.dump(served, f)
+    else:
+        with ShardedIndexClient(idx, _dropin_store(n), collection_names=names, org_id="org-7",
+                                token_embedder=_TokEmb()) as client:
+            got = _dropin_calls(client, n, d)
+        with open(os.path.join(out_dir, "got.json"), "w") as f:
+            json.dump(got, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_dropin_client_on_one_gpu(T, tmp_path):
+    """Row e2: ``RAG2Retriever.retrieve()`` and ``search_knowledge_base()`` over a DOCUMENT-SHARDED
+    index (two processes sharing this GPU, rank 0 the ShardedIndexClient, rank 1 in
+    ShardWorker.serve(); gloo standing in for RCCL) return the contexts -- ids, per-channel ranks,
+    float64 RRF scores, MaxSim rerank scores, parent texts, tool dicts, refusals -- of the
+    one-shard GpuIndexClient over the whole corpus."""
+    import json
+    import os
+    import torch.multiprocessing as mp
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.backend import GpuIndexClient
+    n, d, world = 30000, 768, 2
+    port = 30900 + os.getpid() % 1500
+    mp.spawn(_sharded_client_worker, args=(world, port, n, d, str(tmp_path)), nprocs=world, join=True)
+    got = json.load(open(tmp_path / "got.json"))
+    assert json.load(open(tmp_path / "served1.json")) > 20      # every RPC of every call reached the worker
+    csr, idf, avgdl, v = lexical_fixture(T, n)
+    g = synth.build_graph(n)
+    idx = (T.GpuIndex().set_dense(synth.dense_rows(0, n, d))
+           .set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+           .set_graph(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf)
+           .set_tokens(synth.doc_tokens(0, n, 32, 64)))
+    one = GpuIndexClient(idx, _dropin_store(n), org_id="org-7", token_embedder=_TokEmb())
+    exp = json.loads(json.dumps(_dropin_calls(one, n, d)))
+    assert len(got["retrieve"]) == len(exp["retrieve"]) == 4
+    for gq, eq in zip(got["retrieve"], exp["retrieve"]):
+        assert len(gq) == len(eq) > 0
+        for gc, ec in zip(gq, eq):
+            assert gc[:5] == ec[:5] and gc[6] == ec[6]          # id, three ranks, float64 RRF score, parent text
+            assert (gc[5] is None) == (ec[5] is None) and (gc[5] is None or abs(gc[5] - ec[5]) < 1e-6)
+    assert any(c[3] is not None for ctx in got["retrieve"] for c in ctx)          # the graph channel answered
+    assert any(c[5] is not None for ctx in got["retrieve"] for c in ctx)          # the rerank leg ran
+    # 'faq' = every fifth chunk (the graph channel takes no collection filter, reference retrieval.py:316-356)
+    assert all(int(c[0][1:]) % 5 == 0 for c in got["retrieve"][1] if c[1] is not None or c[2] is not None)
+    assert got["tool"] == exp["tool"] and got["tool"][0]["result_count"] == 5 and got["tool"][2]["refused"]
+
+
 def test_gather_topk_over_rccl_single_rank(T):
     """The ``nccl`` (= RCCL) branch of the exchange -- all_gather_into_tensor on device tensors --
     run with a 1-rank process group on this GPU, merge included."""

@@ -181,17 +181,22 @@ class GpuIndexClient:
     """Supabase-shaped facade over (GpuIndex, CorpusStore)."""
 
     defers_readback = True   # rag2_lexical_search honours ``_defer`` (see _lexical)
+    sets_collections = True  # derives the index's per-doc collection ids from the store's rows
 
     def __init__(self, index: GpuIndex, store: CorpusStore, org_id: Optional[str] = None,
                  token_embedder: Any = None, lexical_and: bool = False,
-                 image_index: Optional[GpuIndex] = None, image_rows: Any = None):
+                 image_index: Optional[GpuIndex] = None, image_rows: Any = None,
+                 collection_names: Optional[Sequence[str]] = None):
         """lexical_and: rank only chunks holding EVERY query term, as the reference's
         ``plainto_tsquery`` does (rag2_schema.sql:365); default is BM25's OR form, the
         north star's and the oracle's.
         image_index / image_rows: the legacy image channel (``kb_chunks_image_search``,
         20260113_add_kb_chunks.sql:236-268): a second dense index over the ``vector_image`` of the
         chunks that have one (``vector_image IS NOT NULL``), row j of it being store row
-        ``image_rows[j]``."""
+        ``image_rows[j]``.
+        collection_names: fixes the collection name -> id mapping (sorted names of the WHOLE
+        corpus): the shards of a document-sharded index must agree on it (sharded_client.py);
+        default: the names this store's rows carry."""
         self.lexical_and = bool(lexical_and)
         self.image_index = image_index
         self.image_rows = None if image_rows is None else [int(r) for r in image_rows]
@@ -204,10 +209,13 @@ class GpuIndexClient:
         self._pin: Dict[Any, list] = {}   # reusable pinned staging buffers (one query per call)
         # collection names -> ids; the filter itself runs on the device, before the ranking
         self._coll_id: Dict[str, int] = {}
+        if collection_names is not None:
+            self._coll_id = {c: i for i, c in enumerate(sorted(set(collection_names)))}
         if store.collections is not None:
-            names = sorted({c for c in store.collections if c is not None})
-            self._coll_id = {c: i for i, c in enumerate(names)}
-            if index.doc_coll is None:
+            if collection_names is None:
+                names = sorted({c for c in store.collections if c is not None})
+                self._coll_id = {c: i for i, c in enumerate(names)}
+            if index.doc_coll is None and self.sets_collections:
                 index.set_collections(np.array([self._coll_id.get(c, -2) if c is not None else -2
                                                 for c in store.collections], dtype=np.int32))
 
@@ -353,6 +361,26 @@ class GpuIndexClient:
         scores, ids = self._download(S, I)
         return self._rows(ids, scores, len(ids), "similarity", limit)
 
+    def _query_terms(self, query: str) -> Optional[List[int]]:
+        """The distinct term ids of the query in order of first appearance (at most
+        THR_BM25_MAX_TERMS), or None when nothing can match."""
+        terms: List[int] = []
+        unknown = False
+        for tok in tokenize(query):
+            t = self.store.vocab.get(tok)
+            if t is None:
+                unknown = True
+            elif t not in terms:
+                terms.append(t)
+        if not terms or getattr(self.index, "lex", True) is None:
+            return None
+        # AND semantics (plainto_tsquery, rag2_schema.sql:365): a token no chunk holds, or a term
+        # the kernel's term list would have to drop, makes the conjunction unsatisfiable -- the
+        # SQL returns no rows, so does this (the OR form just ignores what it does not know)
+        if self.lexical_and and (unknown or len(terms) > N.THR_BM25_MAX_TERMS):
+            return None
+        return terms[: N.THR_BM25_MAX_TERMS]
+
     def _lexical(self, query: str, limit: int, collection, defer: bool = False):
         """defer=True (``_defer`` in the RPC's params; RAG2Retriever sets it): the kernels are
         enqueued on the index's side stream and the rows are read back when first looked at --
@@ -364,22 +392,9 @@ class GpuIndexClient:
                 pending.materialize()   # read it back before the kernels of this one are enqueued
             except Exception:           # (its own caller sees that failure when it looks at the rows)
                 pass
-        terms: List[int] = []
-        unknown = False
-        for tok in tokenize(query):
-            t = self.store.vocab.get(tok)
-            if t is None:
-                unknown = True
-            elif t not in terms:
-                terms.append(t)
-        if not terms or self.index.lex is None:
+        terms = self._query_terms(query)
+        if terms is None:
             return []
-        # AND semantics (plainto_tsquery, rag2_schema.sql:365): a token no chunk holds, or a term
-        # the kernel's term list would have to drop, makes the conjunction unsatisfiable -- the
-        # SQL returns no rows, so does this (the OR form just ignores what it does not know)
-        if self.lexical_and and (unknown or len(terms) > N.THR_BM25_MAX_TERMS):
-            return []
-        terms = terms[: N.THR_BM25_MAX_TERMS]
         # (fixed width: one pinned buffer, one workspace size, whatever the number of terms)
         qt = self._upload(terms + [-1] * (N.THR_BM25_MAX_TERMS - len(terms)), torch.int32, self.index.device)
         k = min(N.THR_TOPK_MAX, limit)

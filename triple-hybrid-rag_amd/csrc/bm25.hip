@@ -171,7 +171,8 @@ constexpr int BM_EXTRA_ITEMS = 16384;  // item list capacity = 2 * n_queries + t
 constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
 constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
                                        // call spreads its 75 K postings over nine workgroups
-constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_THREADS = 256;       // bm25_plan_kernel: one query per thread in as many workgroups as that takes (<= 64);
+constexpr int PLAN_MAX_BLOCKS = 64;     // the workgroup that finishes last cuts the slices and writes the item list
 
 __device__ __forceinline__ int bm_slices(long long tot, long long target);
 // stage-A slices of a query with dense terms: none when its other terms have no posting
@@ -197,11 +198,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_SA,
     int32_t* __restrict__ q_pmask, int32_t* __restrict__ q_item0,
     int32_t* __restrict__ q_long, int32_t* __restrict__ q_terms, int2* __restrict__ items) {
+    // Part 1, every workgroup: what a query is made of (its own load chains -- term ids, then list
+    // lengths / bounds / row slots -- are the kernel's time: one query per thread, the workgroups of
+    // the grid on different CUs; round 3 ran this on ONE workgroup, two queries per thread: 62 us)
     __shared__ int red[PLAN_THREADS];
-    const int per = (nq + PLAN_THREADS - 1) / PLAN_THREADS;
-    const int q0 = threadIdx.x * per;
-    const int q1 = q0 + per < nq ? q0 + per : nq;
-    for (int q = q0; q < q1; ++q) {
+    int n_dp = 0;
+    for (int q = blockIdx.x * PLAN_THREADS + threadIdx.x; q < nq; q += gridDim.x * PLAN_THREADS) {
         int nt = 0, lng = 0;
         long long tot = 0, best = -1;
         bool dead = false;   // AND mode: a term outside the vocabulary is held by no doc
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
                         if (len_[t] > best) { best = len_[t]; lng = t; }   // (the longest WALKED list cuts the stage-A slices)
                     }
                 }
-                if (pmask) atomicAdd(&ctl[3], 1);
+                if (pmask) ++n_dp;
             }
         } else {
             for (int t = 0; t < nt; ++t) {
@@ -302,11 +304,33 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         q_nt[q] = nt;
         q_long[q] = lng;
     }
+    {   // queries with probed terms: one atomic per wave
+        for (int o = WAVE / 2; o > 0; o >>= 1) n_dp += __shfl_down(n_dp, o, WAVE);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && n_dp) atomicAdd(&ctl[3], n_dp);
+    }
+    // Part 2, the workgroup that finishes last: slice size, item list.  (Its reads of the other
+    // workgroups' per-query words go to L2: agent-scope atomic loads.)
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&ctl[6], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    auto tot_of = [&](int q) -> long long {
+        return (long long)__hip_atomic_load(&q_tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    const int per = (nq + PLAN_THREADS - 1) / PLAN_THREADS;
+    const int q0 = threadIdx.x * per < nq ? threadIdx.x * per : nq;
+    const int q1 = q0 + per < nq ? q0 + per : nq;
     // slice size: what gives every workgroup slot of the grid an item, between one pass and three
     __shared__ long long red64[PLAN_THREADS];
     {
         long long t = 0;   // (a stage-B sweep counts one unit per doc)
-        for (int q = q0; q < q1; ++q) t += q_tot[q] >= 0 ? q_tot[q] : -q_tot[q] - 1 + n_docs;
+        for (int q = q0; q < q1; ++q) {
+            const long long v = tot_of(q);
+            t += v >= 0 ? v : -v - 1 + n_docs;
+        }
         red64[threadIdx.x] = t;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
@@ -319,9 +343,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     int total = 0, mine = 0;
     for (;;) {
         mine = 0;
-        for (int q = q0; q < q1; ++q)
-            mine += q_tot[q] >= 0 ? bm_slices(q_tot[q], target)
-                                  : bm_slices_a(-q_tot[q] - 1, target) + bm_slices(n_docs, target);
+        for (int q = q0; q < q1; ++q) {
+            const long long v = tot_of(q);
+            mine += v >= 0 ? bm_slices(v, target) : bm_slices_a(-v - 1, target) + bm_slices(n_docs, target);
+        }
         red[threadIdx.x] = mine;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
@@ -350,10 +375,11 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     int rest = (red[threadIdx.x] - mine) - q0;   // slices s >= 1 of the queries before this thread's
     for (int q = q0; q < q1; ++q) {
         int S = 0;
-        if (q_tot[q] >= 0) {
-            S = bm_slices(q_tot[q], target);
+        const long long v = tot_of(q);
+        if (v >= 0) {
+            S = bm_slices(v, target);
         } else {
-            const int SA = bm_slices_a(-q_tot[q] - 1, target);
+            const int SA = bm_slices_a(-v - 1, target);
             q_SA[q] = SA;
             S = SA + bm_slices(n_docs, target);
         }
@@ -478,7 +504,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     double* __restrict__ slice_s, int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt,
     double* __restrict__ out_s, int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt
 #ifdef BM_STAMPS
-    , unsigned long long* __restrict__ stamps
+    , unsigned long long* __restrict__ stamps, unsigned long long* __restrict__ walk_log
 #endif
     ) {
 #ifdef BM_STAMPS
@@ -540,6 +566,10 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
         __syncthreads();
         const int item = cur_item;
         if (item >= n_items) break;   // (uniform: every workgroup of the grid ends here)
+#ifdef BM_STAMPS
+        const unsigned long long item_t0 = __builtin_readcyclecounter();
+        int item_passes = 0;
+#endif
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
         // a query with dense terms: its first q_SA slices are stage A's (DP), the rest bm25_window_kernel's
@@ -626,6 +656,9 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
         BM_STAMP(1);
 
         while (remaining > 0) {
+#ifdef BM_STAMPS
+            ++item_passes;
+#endif
             // ---- quotas: the stage is shared out in proportion to what is left of each list ----
             if (threadIdx.x == 0) {
                 // (th_glob: read at the item's start and again in every staging interval -- the load
@@ -1261,6 +1294,14 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
         BM_STAMP(11);
 #ifdef BM_STAMPS
         ++stamp_items;
+        if (threadIdx.x == 0 && walk_log) {
+            int tot_ = 0;
+            for (int t = 0; t < nt; ++t) tot_ += tr[t].len;
+            walk_log[4 * (size_t)item] = ((unsigned long long)q << 32) | (unsigned)((sl << 16) | ((DP ? 1 : 0) << 8) | nt);
+            walk_log[4 * (size_t)item + 1] = (unsigned long long)tot_;
+            walk_log[4 * (size_t)item + 2] = __builtin_readcyclecounter() - item_t0;
+            walk_log[4 * (size_t)item + 3] = (unsigned long long)item_passes;
+        }
 #endif
     }
 #ifdef BM_STAMPS
@@ -1274,23 +1315,65 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 // Between stage A and stage B: the sweeps that are still needed.  The docs of a sweep hold none of
 // the query's other terms, so a score there is at most the sum of the dense terms' bounds (added
 // out of order: hence the margin); stage A is complete, and when that sum stays below its
-// threshold no doc of the sweep can enter the top-k -- the item is closed with an empty list.
-// The others are listed for bm25_window_kernel.
-__global__ __launch_bounds__(256) void bm25_sweep_filter_kernel(
-    int32_t* __restrict__ ctl, const int2* __restrict__ items, const int32_t* __restrict__ q_SA,
-    const double* __restrict__ q_dub, const unsigned long long* __restrict__ theta_glob,
-    int32_t* __restrict__ slice_cnt, int32_t* __restrict__ sweep_items) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= ctl[0]) return;
-    const int2 it = items[item];
-    const int SA = q_SA[it.x];
-    if (SA < 0 || it.y < SA) return;
-    const unsigned long long g = theta_glob[it.x];
-    if (g && q_dub[it.x] * (1.0 + 1e-12) < dkey_inv(g)) {
-        slice_cnt[item] = 0;   // (a threshold exists: the query has stage-A slices, the lists are merged)
-        return;
+// threshold no doc of the sweep can enter the top-k -- the query's sweep slices are closed with
+// empty lists.  The others are listed for bm25_window_kernel SLICE-MAJOR: the first slice of every
+// sweeping query, then the second of every one, ... -- the workgroups of the persistent grid then
+// start on different queries, and a query's later slices find the threshold its first one has
+// published (query-major, the first 512 items were the six slices of 85 queries, all started
+// together and all without a threshold: every doc of their first windows scored in full).
+// One workgroup: rank of a query among the sweeping ones by a block scan, no atomics, a
+// deterministic list.
+constexpr int FILTER_THREADS = 1024;
+__global__ __launch_bounds__(FILTER_THREADS) void bm25_sweep_filter_kernel(
+    int32_t* __restrict__ ctl, int nq, int slice_major, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
+    const int32_t* __restrict__ q_item0, const double* __restrict__ q_dub,
+    const unsigned long long* __restrict__ theta_glob, int32_t* __restrict__ slice_cnt,
+    int32_t* __restrict__ sweep_items) {
+    __shared__ int red[FILTER_THREADS];
+    const int per = (nq + FILTER_THREADS - 1) / FILTER_THREADS;
+    const int q0 = (int)threadIdx.x * per < nq ? (int)threadIdx.x * per : nq;
+    const int q1 = q0 + per < nq ? q0 + per : nq;
+    auto item_of = [&](int q, int s) -> int { return s == 0 ? q : q_item0[q] + s; };
+    auto sweeps = [&](int q) -> bool {   // (and closes the slices of a sweep that is ruled out)
+        const int SA = q_SA[q];
+        if (SA < 0) return false;
+        const unsigned long long g = theta_glob[q];
+        if (g && q_dub[q] * (1.0 + 1e-12) < dkey_inv(g)) {
+            // (a threshold exists: the query has stage-A slices, the lists are merged)
+            for (int s = SA; s < q_S[q]; ++s) slice_cnt[item_of(q, s)] = 0;
+            return false;
+        }
+        return true;
+    };
+    int mine = 0;
+    unsigned long long live = 0ull;   // (per <= 64 for batches of up to 65536 queries; beyond, recomputed)
+    for (int q = q0; q < q1; ++q)
+        if (sweeps(q)) {
+            ++mine;
+            if (q - q0 < 64) live |= 1ull << (q - q0);
+        }
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < FILTER_THREADS; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? red[threadIdx.x - o] : 0;
+        __syncthreads();
+        red[threadIdx.x] += v;
+        __syncthreads();
     }
-    sweep_items[atomicAdd(&ctl[5], 1)] = item;
+    const int n_sw = red[FILTER_THREADS - 1];
+    int rank = red[threadIdx.x] - mine;
+    int n_items = 0;
+    for (int q = q0; q < q1; ++q) {
+        const bool on = q - q0 < 64 ? ((live >> (q - q0)) & 1ull) != 0ull : sweeps(q);
+        if (!on) continue;
+        const int SA = q_SA[q], SB = q_S[q] - SA;   // (SB is the same for every query of a batch)
+        for (int s = 0; s < SB; ++s)
+            sweep_items[slice_major ? (int64_t)s * n_sw + rank : (int64_t)rank * SB + s] = item_of(q, SA + s);
+        n_items = SB;
+        ++rank;
+    }
+    // the number of sweep items: n_sw * SB (any thread with a sweeping query knows SB)
+    if (n_items && red[threadIdx.x] == n_sw && mine > 0) ctl[5] = n_sw * n_items;   // (the last thread that holds one)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1327,6 +1410,7 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
 #ifdef BM_STAMPS
     unsigned long long stamp_acc[BM_NSTAMP] = {0};
     unsigned long long stamp_last = __builtin_readcyclecounter(), stamp_items = 0;
+    unsigned long long* item_log = stamps + (size_t)2 * 4096 * (BM_NSTAMP + 1);   // behind the three stamp areas: 4 words per sweep item
 #endif
     constexpr int BIT_WORDS = 8192;                   // the segment's bitmap: 256 K docs
     constexpr int SEG_DOCS = BIT_WORDS * 32;
@@ -1358,6 +1442,10 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
         if (threadIdx.x == 0) cur_item = atomicAdd(&ctl[2], 1);
         __syncthreads();
         if (cur_item >= n_sweeps) break;
+#ifdef BM_STAMPS
+        const unsigned long long item_t0 = __builtin_readcyclecounter();
+        int item_passes = 0, item_surv = 0;
+#endif
         const int item = sweep_items[cur_item];
         const int2 it = items[item];
         const int q = it.x, sl = it.y;
@@ -1393,13 +1481,20 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
             n_walked += t_row[t] < 0 && tr[t].len > 0 ? 1 : 0;
             np += t_row[t] >= 0 ? 1 : 0;
         }
-        if (threadIdx.x == 0) {   // integer weights of the quantised impacts (see bm25_topk_kernel)
+        if (threadIdx.x == 0) {
+            // integer weights of the quantised impacts (see bm25_topk_kernel) -- of the PROBED terms
+            // only: a doc of the sweep holds no walked term, so its score is the probed terms' alone,
+            // and the 248 units go to them.  (Shared out over all the query's terms -- round 3 -- a lone
+            // stop word beside three rare walked terms got a weight of ceil(1.6) = 2: a bound 22 % above
+            // the score, every doc of the shard "survived" and was scored in full: six items of 1.3 M
+            // cycles each in a kernel whose workgroups average 0.64 M -- the sweep kernel's length.)
             const double c = (k1 + 1.0) / 255.0;
             double sum = 0.0;
-            for (int t = 0; t < nt; ++t) sum += t_idf[t] * c;
-            const double scale = 248.0 / sum;
+            for (int t = 0; t < nt; ++t)
+                if (t_row[t] >= 0) sum += t_idf[t] * c;
+            const double scale = sum > 0.0 ? 248.0 / sum : 1.0;
             for (int t = 0; t < nt; ++t) {
-                const int w = (int)ceil(t_idf[t] * c * scale);
+                const int w = t_row[t] >= 0 ? (int)ceil(t_idf[t] * c * scale) : 0;
                 t_w[t] = w < 1 ? 1 : w;
             }
             acc_scale = scale;
@@ -1412,7 +1507,7 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
         }
         __syncthreads();
         // what the coming pass needs: its window and its threshold in accumulator units
-        auto prepare = [&]() {
+        auto prepare = [&](int last_w, int last_ns) {
             if (threadIdx.x == 0) {
                 const bool have_local = b_cnt >= k && th_s > -INFINITY;
                 const bool have_th = have_local || th_glob > -INFINITY;
@@ -1420,8 +1515,14 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                 th = th_glob > th ? th_glob : th;
                 const double tq = have_th ? floor(th * acc_scale * (1.0 - 1e-12)) : 0.0;
                 p_thq = tq < 0.0 ? 0 : tq > 70000.0 ? 70000 : (int)tq;
-                // without a threshold every doc that holds a term is scored in full: a short window gets one
-                p_wmax = have_th || S == 1 ? BW_PAD : 2048;
+                // without a threshold every doc that holds a term is scored in full: a short window gets
+                // one; and a threshold that let more than 1/16 of the last window through is still a poor
+                // one (the k docs seen so far need not hold the term that decides the ranking: a stop
+                // word with idf 0.01 beside a 2 % term with idf 3.8 had 35 K survivors in the 64 K window
+                // that followed the first 2 K one): the window then grows fourfold per pass, not at once
+                p_wmax = !(have_th || S == 1) ? 2048
+                         : (last_w > 0 && last_ns * 16 > last_w && last_w * 4 < BW_PAD) ? (last_w * 4 > 2048 ? last_w * 4 : 2048)
+                                                                                       : BW_PAD;
                 n_surv = 0;
             }
         };
@@ -1466,7 +1567,7 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                     }
                 }
             }
-            prepare();
+            prepare(0, 0);
             __syncthreads();
             BM_STAMP(3);
             int64_t cursor = g0;
@@ -1603,6 +1704,10 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                 const int ns = n_surv;
                 BM_COUNT(17, ns);
                 BM_COUNT(18, (ns + BW_THREADS - 1) / BW_THREADS);
+#ifdef BM_STAMPS
+                ++item_passes;
+                item_surv += ns;
+#endif
                 if (ns <= SURV_CAP) {
                     phase2(ns);
                 } else {   // (passes without a threshold) SURV_CAP slots at a time
@@ -1635,12 +1740,20 @@ __global__ __launch_bounds__(BW_THREADS, 4) void bm25_window_kernel(
                     if (g > th_glob) th_glob = g;
                 }
                 cursor = end;
-                prepare();
+                prepare(w, ns);
                 __syncthreads();
                 BM_STAMP(10);
             }
         }
         const int n = tk.finish();
+#ifdef BM_STAMPS
+        if (threadIdx.x == 0) {
+            item_log[4 * (size_t)cur_item] = ((unsigned long long)q << 32) | (unsigned)(((sl - SA) << 16) | (np << 8) | n_walked);
+            item_log[4 * (size_t)cur_item + 1] = item_t0;
+            item_log[4 * (size_t)cur_item + 2] = __builtin_readcyclecounter();
+            item_log[4 * (size_t)cur_item + 3] = ((unsigned long long)item_passes << 32) | (unsigned)item_surv;
+        }
+#endif
         if (S == 1) {
             for (int i = threadIdx.x; i < k; i += BW_THREADS) {
                 out_s[(int64_t)q * k + i] = i < n ? b_s[i] : -INFINITY;
@@ -1731,7 +1844,7 @@ static BmLayout bm_layout(int nq, int mt, int k) {
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    L.off_ctl = take(sizeof(int32_t) * 8);                 // [0] items, [1] [2] [4] next item of a kernel, [3] queries with dense terms  } zeroed
+    L.off_ctl = take(sizeof(int32_t) * 8);                 // [0] items, [1] [2] [4] next item of a kernel, [3] queries with dense terms, [5] sweeps, [6] plan workgroups done  } zeroed
     L.off_theta = take(sizeof(unsigned long long) * nq);   // shared thresholds (keys)   } per call
     L.off_tot = take(sizeof(int64_t) * nq);
     L.off_dub = take(sizeof(double) * nq);
@@ -1749,7 +1862,7 @@ static BmLayout bm_layout(int nq, int mt, int k) {
     L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
     L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
 #ifdef BM_STAMPS
-    L.off_stamps = take(sizeof(unsigned long long) * 3 * 4096 * (BM_NSTAMP + 1));
+    L.off_stamps = take(sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap));
 #endif
     L.total = off;
     return L;
@@ -1870,6 +1983,9 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
+#ifdef BM_STAMPS
+    hipMemsetAsync(ws + L.off_stamps, 0, sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap), st);
+#endif
     static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1, walk_div = 64, fuse_div = 8;
     if (small < 0) {
         const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
@@ -1892,7 +2008,9 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int grid = bm_num_cus() * (per_cu ? per_cu : (huge ? 1 : big ? 2 : 4));
     if (grid > L.cap) grid = L.cap;
     const int32_t* dslot = (use_dense && use_imp) ? dense_slot : nullptr;
-    hipLaunchKernelGGL(bm25_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
+    int plan_blocks = (n_queries + PLAN_THREADS - 1) / PLAN_THREADS;
+    plan_blocks = plan_blocks > PLAN_MAX_BLOCKS ? PLAN_MAX_BLOCKS : plan_blocks;
+    hipLaunchKernelGGL(bm25_plan_kernel, dim3(plan_blocks), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
                        n_queries, max_terms, L.cap, conjunctive, grid, target_max, walk_div, dslot, term_ub, n_docs, ctl,
                        q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
@@ -1903,7 +2021,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #ifdef BM_STAMPS
     unsigned long long* d_stamps = (unsigned long long*)(ws + L.off_stamps);
     if (grid > 4096) grid = 4096;
-#define BM_STAMP_ARG(DP) , d_stamps + (DP == 1 ? 2 : 0) * (size_t)4096 * (BM_NSTAMP + 1)
+#define BM_STAMP_ARG(DP) , d_stamps + (DP == 1 ? 2 : 0) * (size_t)4096 * (BM_NSTAMP + 1), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1) + 4 * (size_t)L.cap
 #else
 #define BM_STAMP_ARG(DP)
 #endif
@@ -1936,8 +2054,13 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         THR_BM25_LAUNCH_SHAPE(2);
         THR_BM25_LAUNCH_SHAPE(1);
         if ((rc = launch_status())) return rc;
-        hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), 0, st, ctl, items,
-                           q_SA, q_dub, theta, slice_cnt, sweep_items);
+        static int slice_major = -1;
+        if (slice_major < 0) {
+            const char* eo = getenv("THR_BM25_SWEEP_ORDER");   // q(uery-major) / s(lice-major): A/B knob
+            slice_major = !(eo && eo[0] == 'q');
+        }
+        hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3(1), dim3(FILTER_THREADS), 0, st, ctl, n_queries, slice_major, q_S,
+                           q_SA, q_item0, q_dub, theta, slice_cnt, sweep_items);
         int wgrid = bm_num_cus() * 2;
         if (wgrid > L.cap) wgrid = L.cap;
 #ifdef BM_STAMPS
@@ -1975,6 +2098,33 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                 if (names[i][0]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * tot[i] / all);
             for (int i = 14; i < 20; ++i) fprintf(stderr, " %s %.0f", names[i][0] ? names[i] : "#wmax|#singles", tot[i]);
             fprintf(stderr, "\n");
+        }
+        if (dslot) {   // the sweep items one by one: when each started and ended (cycles since the first), its passes and survivors
+            int h_ctl[8];
+            hipMemcpy(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost);
+            const int ns = h_ctl[5];
+            std::vector<unsigned long long> lg((size_t)4 * (ns > 0 ? ns : 1));
+            hipMemcpy(lg.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1), lg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < ns; ++i) {
+                if (lg[4 * i + 1] < t0) t0 = lg[4 * i + 1];
+                if (lg[4 * i + 2] > t1) t1 = lg[4 * i + 2];
+            }
+            fprintf(stderr, "[bm25 sweep items] %d items, %llu cycles from the first start to the last end\n", ns, ns ? t1 - t0 : 0ull);
+            if (getenv("THR_BM25_ITEM_LOG")) {
+                const int ni = h_ctl[0];
+                std::vector<unsigned long long> wl((size_t)4 * (ni > 0 ? ni : 1));
+                hipMemcpy(wl.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1) + 4 * (size_t)L.cap, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                for (int i = 0; i < ni; ++i)
+                    if (wl[4 * i + 2])
+                        fprintf(stderr, "[walk] %d q %llu slice %llu dp %llu nt %llu postings %llu cycles %llu passes %llu\n", i, wl[4 * i] >> 32,
+                                (wl[4 * i] >> 16) & 0xFFFF, (wl[4 * i] >> 8) & 0xFF, wl[4 * i] & 0xFF, wl[4 * i + 1], wl[4 * i + 2], wl[4 * i + 3]);
+            }
+            if (getenv("THR_BM25_ITEM_LOG"))
+                for (int i = 0; i < ns; ++i)
+                    fprintf(stderr, "[item] %d q %llu slice %llu np %llu walked %llu start %llu cycles %llu passes %llu survivors %llu\n", i,
+                            lg[4 * i] >> 32, (lg[4 * i] >> 16) & 0xFFFF, (lg[4 * i] >> 8) & 0xFF, lg[4 * i] & 0xFF, lg[4 * i + 1] - t0,
+                            lg[4 * i + 2] - lg[4 * i + 1], lg[4 * i + 3] >> 32, lg[4 * i + 3] & 0xFFFFFFFFull);
         }
     }
 #endif
