@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--config", choices=CONFIGS + ("all",), default=None,
                     help="pipeline to time; default: all four at N = 1 (headline = dense), dense at N > 1")
+    ap.add_argument("--preset", choices=("configs1", "configs2", "configs3", "configs4"), default=None,
+                    help="a BASELINE.json config at its stated size and layout: configs1 = 1M dense-only; "
+                         "configs2 = 1M dense + BM25 + RRF(0.8/0.7); configs3 = 10M triple-hybrid cut into "
+                         "--gpus document shards; configs4 = the same + MaxSim rerank (sets --docs, --config "
+                         "and, for the 10M-doc ones, --doc-shards N)")
     ap.add_argument("--token-docs", type=int, default=0,
                     help="docs that get a late-interaction token matrix (default: all; 32 KiB each)")
     ap.add_argument("--doc-shards", type=int, default=0,
@@ -84,7 +89,15 @@ def parse():
     ap.add_argument("--shortlist", choices=("auto", "f16-inline", "f16", "f32"), default="auto",
                     help="shortlist scan of the timed path (GpuIndex.set_dense): auto = f16 copy; "
                          "results are the same float64-exact bits in every flavour (DESIGN.md 4.1)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.preset:
+        args.config = {"configs1": "dense", "configs2": "dense_bm25", "configs3": "triple",
+                       "configs4": "triple_rerank"}[args.preset]
+        if args.preset in ("configs3", "configs4"):
+            if args.docs == 1_000_000:      # (an explicit --docs wins: rehearsals run the layout on a small corpus)
+                args.docs = 10_000_000
+            args.doc_shards = args.doc_shards or args.gpus
+    return args
 
 
 def event_ms(fn, reps, torch):
@@ -270,7 +283,7 @@ def main():
             index.docs16, index.doc_rel_err = T._native.dense_quantize_f16(
                 index.docs, keep_copy=name == "f16")
 
-    def committed_pmc():
+    def committed_pmc(n_local=n_local):
         """HBM bytes per launch of the default scan from the committed --pmc pass (profiles/,
         FETCH_SIZE x2 on gfx950): NOT measured in this run, and only quoted for the shape it
         was collected on."""
@@ -283,9 +296,10 @@ def main():
             pass
         return None
 
-    def probe_scan(name, queries_dev=None, reps=None):
+    def probe_scan(name, queries_dev=None, reps=None, B=B):
         """The streaming scan kernel alone: average launch time from HIP events on its stream."""
-        qx = qd if queries_dev is None else queries_dev
+        index, n_local = B.index, B.n_local
+        qx = B.qd if queries_dev is None else queries_dev
         if queries_dev is not None:
             index.dense_search(qx, 100, rescue=False)   # thresholds / query image for this batch
         ms = event_ms(lambda: index.scan_probe(qx), reps or args.probe_reps, torch)
@@ -301,7 +315,7 @@ def main():
                "launch_ms": round(ms, 4), "flops_per_launch": flops}
         # what one launch has to read: the float16 copy (or the float32 rows), once
         out["traffic_algorithmic"] = n_local * args.dim * (2 if name == "f16" else 4)
-        pm = committed_pmc() if (name == "f16" and queries_dev is None) else None
+        pm = committed_pmc(n_local) if (name == "f16" and queries_dev is None) else None
         if pm:
             out["traffic"] = pm["hbm_read_bytes_per_launch"]
             out["traffic_source"] = (os.path.relpath(PMC_PROFILE, ROOT) + " (separate rocprofv3 --pmc run, same "
@@ -318,27 +332,48 @@ def main():
     qps = args.steps * nq * n_replicas / elapsed   # every replica serves its own batch
     roofline = probe_scan(primary)
     head_ids = res.ids.clone()
-    per_rank = None
-    if world > 1:
-        # where this rank's share of a step goes: the scan alone, the exchange alone (the same
-        # all-gather on this step's own lists), and everything else of the step
+    def rank_breakdown(B, elapsed, roof):
+        """Where this rank's share of a step goes: the scan alone, the exchange alone (the same
+        all-gather on this step's own lists), and everything else of the step."""
         from triple_hybrid_rag_amd.distributed import gather_topk_many
-        Ss_, Is_, _, _ = index.dense_search(qd, 100, sync=False)
+        Ss_, Is_, _, _ = B.index.dense_search(B.qd, 100, sync=False)
         pairs = [(Ss_, Is_)]
         if head_cfg != "dense":
-            Sl_, Il_, _ = index.bm25_search(qtd, 50)
+            Sl_, Il_, _ = B.index.bm25_search(B.qtd, 50)
             pairs.append((Sl_, Il_))
         if head_cfg.startswith("triple"):
-            Sg_, Ig_, _ = index.graph_search(sd, 50, 2)
+            Sg_, Ig_, _ = B.index.graph_search(B.sd, 50, 2)
             pairs.append((Sg_, Ig_))
-        ex_ms = event_ms(lambda: gather_topk_many(pairs, group), 5, torch)
+        ex_ms = event_ms(lambda: gather_topk_many(pairs, B.group), 5, torch)
         step_ms = 1e3 * elapsed / args.steps
-        per_rank = {"step_ms": round(step_ms, 3), "scan_ms": roofline["launch_ms"],
-                    "exchange_ms": round(ex_ms, 3),
-                    "fixed_ms": round(step_ms - roofline["launch_ms"] - ex_ms, 3),
-                    "exchange_bytes_per_rank": int(sum(2 * 8 * s_.numel() for s_, _ in pairs)),
-                    "note": "rank 0; fixed = embed post-processing, threshold sample + select, shortlist, "
-                            "float64 rescoring, merge, fusion"}
+        return {"step_ms": round(step_ms, 3), "scan_ms": roof["launch_ms"], "exchange_ms": round(ex_ms, 3),
+                "fixed_ms": round(step_ms - roof["launch_ms"] - ex_ms, 3),
+                "exchange_bytes_per_rank": int(sum(2 * 8 * s_.numel() for s_, _ in pairs)),
+                "shard_docs": B.n_local,
+                "note": "rank 0; fixed = embed post-processing, threshold sample + select, shortlist, "
+                        "float64 rescoring, merge, fusion"}
+
+    per_rank = strong = None
+    if world > 1:
+        per_rank = rank_breakdown(B, elapsed, roofline)
+        # The north star's layout -- the corpus cut into N document shards, ONE batch served by all
+        # N GPUs, per-shard top-k merged through the all-gather (SURVEY 8e) -- is reported in every
+        # N > 1 line, whatever layout the headline ran: the same run, the same corpus and batch.
+        if B.n_replicas == 1:
+            strong = {"layout": f"doc-shard x{world}", "same_run_as_the_headline": True, "scaling": "strong",
+                      "ms_per_step": round(1e3 * elapsed / args.steps, 3), "value": round(qps, 1),
+                      "unit": "queries/s", "per_rank_ms": per_rank}
+        else:
+            B2 = build(world)
+            _, resc2, el2 = measure(step_fn(head_cfg, B2))
+            roof2 = probe_scan(primary, B=B2)
+            strong = {"layout": f"doc-shard x{world}", "same_run_as_the_headline": False, "scaling": "strong",
+                      "ms_per_step": round(1e3 * el2 / args.steps, 3), "value": round(args.steps * nq / el2, 1),
+                      "unit": "queries/s", "rescued_queries": resc2,
+                      "scan": {k_: roof2[k_] for k_ in ("achieved", "peak", "unit", "frac", "launch_ms")},
+                      "per_rank_ms": rank_breakdown(B2, el2, roof2)}
+            del B2
+            torch.cuda.empty_cache()
 
     # ---- the other configs (N = 1 default run): same corpus, same batch ----
     cfg_out = {}
@@ -513,7 +548,7 @@ def main():
             # the hybrid pipelines against the oracle's channels + fusion, on a bounded sample
             sub = list(range(0, nq, max(1, nq // 32)))[:32]
             _, Il_o = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf,
-                                  float(sdl.item()) / args.docs, qt[sub], n_local, 50)
+                                  B.avgdl, qt[sub], n_local, 50)
             _, Ig_o = O.graph_topk(graph.ent_rowptr, graph.ent_col, graph.men_rowptr, graph.men_chunk,
                                    graph.men_conf, seeds[sub], 2, n_local, 50)
             block = 8192
@@ -581,7 +616,7 @@ def main():
                                + ("" if head_cfg == "dense" else " + BM25 top-50" + (" + graph top-50" if head_cfg.startswith("triple") else ""))
                                + " -> weighted RRF -> fused top-10" + (" of the MaxSim-reranked top-100" if head_cfg == "triple_rerank" else ""),
                        "lexical_mix": args.lexical_mix if head_cfg != "dense" else None,
-                       "per_rank_ms": per_rank},
+                       "per_rank_ms": per_rank, "strong_doc_sharded": strong},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cfg_out:

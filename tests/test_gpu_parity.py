@@ -1339,6 +1339,35 @@ def test_sharded_dropin_client_on_one_gpu(T, tmp_path):
     assert got["tool"] == exp["tool"] and got["tool"][0]["result_count"] == 5 and got["tool"][2]["refused"]
 
 
+def test_dense_rows_of_a_length_no_scan_is_built_for(T, caplog):
+    """The reference's legacy RAG 1.0 store keeps 4000-d rows (src/voice_agent/config.py:216,
+    database/migrations/20260113_halfvec_4000.sql:70-105): ``set_dense`` routes such a row length
+    to the exhaustive float64 path -- with a warning, not THR_ERR_UNSUPPORTED -- and the legacy
+    ``kb_chunks_vector_search`` RPC answers with the oracle's ids and float64 cosines."""
+    import logging
+    from triple_hybrid_rag_amd.backend import CorpusStore, GpuIndexClient
+    n, d = 3000, 4000
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[7] = 0.0                                   # a chunk without an embedding
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    with caplog.at_level(logging.WARNING, logger="triple_hybrid_rag_amd.index"):
+        idx = T.GpuIndex().set_dense(x)
+    assert idx.shortlist == "exact" and any("4000" in r.getMessage() for r in caplog.records)
+    S, I, cnt, resc = idx.dense_search(dev(q), 50)
+    Se, Ie, _ = CO.dense_topk_exact(x, q, 50)
+    assert resc == 0 and np.array_equal(I.cpu().numpy(), np.stack(Ie)) and np.array_equal(S.cpu().numpy(), np.stack(Se))
+    res = idx.retrieve_batch(dev(q), top_k=10)   # the batch pipeline over it: dense -> RRF
+    for i in range(6):
+        assert list(res.ids[i].cpu().numpy()) == O.fused_topk_ids(None, list(Ie[i]), None, 10)[0]
+    with pytest.raises(T._native.NativeError, match="row length"):
+        T.GpuIndex().set_dense(x, shortlist="f16")
+    client = GpuIndexClient(idx, CorpusStore.synthetic(n), org_id="org")
+    rows = client.rpc("kb_chunks_vector_search", {"p_org_id": "org", "p_embedding": q[2].tolist(), "p_limit": 5}).execute().data
+    assert [r["id"] for r in rows] == [f"c{i}" for i in Ie[2][:5]]
+    assert [r["similarity"] for r in rows] == [float(v) for v in Se[2][:5]]
+
+
 def test_gather_topk_over_rccl_single_rank(T):
     """The ``nccl`` (= RCCL) branch of the exchange -- all_gather_into_tensor on device tensors --
     run with a 1-rank process group on this GPU, merge included."""
@@ -1617,8 +1646,10 @@ def test_cli_config0_100_queries_match_the_oracle_pipeline(T):
 
 
 def test_bench_multi_rank_control_flow():
-    """bench.py --gpus 2 end to end on one GPU (THR_BENCH_REHEARSAL: both ranks on cuda:0, gloo in
-    place of RCCL): document sharding, exchange, merge and the single JSON line of rank 0."""
+    """bench.py --gpus N end to end on one GPU (THR_BENCH_REHEARSAL: all ranks on cuda:0, gloo in
+    place of RCCL): document sharding, replicas, exchange, merge and the single JSON line of rank 0,
+    which at N > 1 always carries the north star's layout (``config.strong_doc_sharded``: the corpus
+    cut into N document shards, one batch served by all N GPUs) next to whatever layout ran."""
     import json
     import os
     import subprocess
@@ -1626,26 +1657,37 @@ def test_bench_multi_rank_control_flow():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, THR_BENCH_REHEARSAL="1")
     port = 29800 + os.getpid() % 1000
-    for extra, label, cfg in (([], "doc-shard x2", []),
-                              (["--doc-shards", "1"], "doc-shard x1 x 2 replicas", []),
-                              ([], "doc-shard x2", ["--config", "triple_rerank", "--token-docs", "20000"])):
+    for gpus, extra, label, pipeline in (
+            (2, [], "doc-shard x2", "dense"),
+            (2, ["--doc-shards", "1"], "doc-shard x1 x 2 replicas", "dense"),
+            (2, ["--config", "triple_rerank", "--token-docs", "20000"], "doc-shard x2", "triple_rerank"),
+            (4, ["--doc-shards", "2", "--config", "dense_bm25"], "doc-shard x2 x 2 replicas", "dense_bm25"),
+            (2, ["--preset", "configs3"], "doc-shard x2", "triple")):     # configs[3]'s layout, one flag away
         out = subprocess.run(
-            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-             "--gpus", "2", "--steps", "2", "--warmup", "1", "--docs", "40000", "--queries", "192",
-             "--no-extras", "--no-cpu-baseline"] + extra + cfg,
+             "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--docs", "40000", "--queries", "192",
+             "--no-extras", "--no-cpu-baseline"] + extra,
             env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1
         rec = json.loads(lines[0])
-        assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+        assert rec["n_gpus"] == gpus and rec["steps"] == 2 and rec["value"] > 0
         assert rec["config"]["parallelism"].startswith(label) and rec["config"]["rescued_queries"] == 0
-        assert rec["scaling"] == ("weak" if "replicas" in label else "strong")
+        replicas = "replicas" in label
+        assert rec["scaling"] == ("weak" if replicas else "strong")
         # where a rank's share of the step goes (scan / exchange / the rest)
         assert set(rec["config"]["per_rank_ms"]) >= {"step_ms", "scan_ms", "exchange_ms", "fixed_ms"}
-        assert rec["config"]["collective_backend"] == "gloo" and rec["config"]["world_size_seen"] == 2
-        assert rec["config"]["pipeline"] == (cfg[1] if cfg else "dense")
+        assert rec["config"]["collective_backend"] == "gloo" and rec["config"]["world_size_seen"] == gpus
+        assert rec["config"]["pipeline"] == pipeline
+        strong = rec["config"]["strong_doc_sharded"]
+        assert strong["layout"] == f"doc-shard x{gpus}" and strong["scaling"] == "strong"
+        assert strong["ms_per_step"] > 0 and strong["value"] > 0 and strong["same_run_as_the_headline"] == (not replicas)
+        assert set(strong["per_rank_ms"]) >= {"step_ms", "scan_ms", "exchange_ms", "fixed_ms"}
+        assert strong["per_rank_ms"]["shard_docs"] == 40000 // gpus
+        if not replicas:
+            assert strong["value"] == rec["value"] and strong["ms_per_step"] == rec["ms_per_step"]
         port += 1
 
 

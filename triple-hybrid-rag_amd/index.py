@@ -22,6 +22,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
+import logging
 import os
 import warnings
 
@@ -29,6 +30,8 @@ import numpy as np
 import torch
 
 from . import _native as N
+
+log = logging.getLogger(__name__)
 
 
 @dataclass
@@ -40,6 +43,33 @@ class BatchResult:
     # queries that needed the exhaustive float64 path: an int, or (batch path, so that a batch
     # needs no host synchronisation) a device int32[1] -- int(result.rescued) reads it back
     rescued: object = 0
+
+
+class StepGraph:
+    """One step of the batch pipeline captured as a hipGraph over STATIC buffers: ``fn`` (e.g.
+    ``lambda: index.retrieve_batch(embed_postproc(raw), terms, seeds)``) is run ``warmup`` times --
+    workspaces get allocated, the library's lazily read knobs are read -- and then captured;
+    ``replay()`` re-enqueues the whole kernel sequence, both streams of it, with ONE host call
+    (a step of a 125 K-row shard is ~20 kernels of 5..350 us: launched one by one from Python
+    the host is the bottleneck).  ``result`` is what ``fn`` returned inside the capture: its
+    tensors are rewritten by every replay.  New inputs go in by copying into the tensors ``fn``
+    read (``raw.copy_(...)``): the graph holds their addresses."""
+
+    def __init__(self, fn, warmup: int = 2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
 
 
 class GpuIndex:
@@ -76,8 +106,9 @@ class GpuIndex:
                 return torch.from_numpy(a).to(device=self.device, dtype=dtype)
         return torch.from_numpy(a).to(device=self.device, dtype=dtype)
 
-    SHORTLISTS = ("auto", "f32", "f16", "f16-inline")
+    SHORTLISTS = ("auto", "f32", "f16", "f16-inline", "exact")
     F16_DIMS = (512, 768, 1024)
+    SCAN_DIMS = (256, 512, 768, 1024)   # row lengths the streaming shortlist scans are built for
     AUTO_COPY_FRACTION = 0.25    # of the device's memory: every shard the f16 scans can index (2^25 rows)
     F16_MAX_ROWS = 1 << 25       # per shard: the f16 scans pack (query-in-tile, row) in 32 bits
     F16_MAX_REL_ERR = 2e-3       # ~8x the rounding error of rows in float16's normal range
@@ -90,17 +121,34 @@ class GpuIndex:
           "f16-inline" float32 rows rounded to float16 in registers, f16 matrix cores
                        (64 queries per pass, no extra memory);
           "f16"        additionally keeps a float16 copy of the rows and streams that;
+          "exact"      no shortlist pass: every row scored in float64 (thr_dense_topk_exact) -- any
+                       row length that is a multiple of 4;
           "auto"       an f16 flavour when the dimension has an f16 kernel and every row fits the
                        float16 range -- "f16" while the copy is small next to the device's memory
                        (<= AUTO_COPY_FRACTION of it: a quarter, which covers every shard size the f16 scans
-                       index), "f16-inline" beyond -- else "f32"."""
+                       index), "f16-inline" beyond -- else "f32"; a row length none of the scans is
+                       built for (the reference's legacy RAG 1.0 store keeps 4000-d halfvec rows,
+                       src/voice_agent/config.py:216, 20260113_halfvec_4000.sql:70-105) goes to
+                       "exact" with a logged warning: same bits, O(n * dim) float64 work per query."""
         if shortlist not in self.SHORTLISTS:
             raise ValueError(f"shortlist must be one of {self.SHORTLISTS}")
         self.docs = self._t(docs, torch.float32)
         self.n_docs, self.dim = self.docs.shape
+        if self.dim % 4:
+            raise N.NativeError(f"row length {self.dim} is not a multiple of 4")
         self.dnorm, self.inv_norm = N.doc_norms(self.docs)
         self.docs16, self.doc_rel_err = (None, 0.0)
         auto = shortlist == "auto"
+        if self.dim not in self.SCAN_DIMS and shortlist != "exact":
+            if not auto:
+                raise N.NativeError(f"shortlist={shortlist!r} needs a row length in {self.SCAN_DIMS}, got "
+                                    f"{self.dim}: use shortlist='exact' (or 'auto')")
+            log.warning("dense rows of %d dims: no streaming scan is built for that length, every search "
+                        "scores all %d rows in float64 (thr_dense_topk_exact)", self.dim, self.n_docs)
+            shortlist, auto = "exact", False
+        if shortlist == "exact":
+            self.shortlist = shortlist
+            return self
         if auto:
             shortlist = "f32"
             if self.dim in self.F16_DIMS and self.n_docs < self.F16_MAX_ROWS:
@@ -183,6 +231,8 @@ class GpuIndex:
     def reserve(self, n_queries: int, k: int, kprime: Optional[int] = None) -> "GpuIndex":
         """Allocate the dense workspaces for batches of ``n_queries`` up front (index set-up), so
         that no search pays a device allocation."""
+        if self.shortlist == "exact":
+            return self
         if self.shortlist != "f32":
             kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 92)))
             self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim, n_queries, kp))
@@ -226,6 +276,9 @@ class GpuIndex:
                     n_rescued = n_rescued + r_
                 return S, I, cnt, n_rescued
         dc, qc = self._qcoll(collections, nq)
+        if self.shortlist == "exact":
+            S, I, cnt, _ = N.dense_topk_exact(self.docs, self.dnorm, queries, k, self.doc_base, dc, qc)
+            return S, I, cnt, (0 if sync else torch.zeros(1, dtype=torch.int32, device=self.device))
         if self.shortlist != "f32":
             # tau must sit clearly below the k-th score for the quantisation-aware certificate:
             # k' = 192 puts it ~6e-3 below on a 1M-row corpus, ~6x the f16 error bound
@@ -254,8 +307,8 @@ class GpuIndex:
     def scan_probe(self, queries: torch.Tensor) -> None:
         """Launch ONLY the streaming scan kernel of the last dense_search (same workspace, so the
         thresholds tau are the ones that search computed): the timing/roofline probe."""
-        if self._ws is None:
-            raise N.NativeError("scan_probe needs a preceding dense_search on this index")
+        if self._ws is None or self.shortlist == "exact":
+            raise N.NativeError("scan_probe needs a preceding dense_search on this index (and a shortlist scan)")
         queries = self._t(queries, torch.float32)
         if self.shortlist != "f32":
             N.dense_scan_probe_f16(self.docs, self.docs16, self.inv_norm, queries, self._ws)
@@ -283,16 +336,20 @@ class GpuIndex:
         # one, or the side stream of side_channels / GpuIndexClient's deferred RPC): the stream of
         # this call waits for the previous call's kernels before its memset touches the workspace
         cur = torch.cuda.current_stream(self.device)
-        if self._lex_done is not None:
+        # (inside a hipGraph capture the order is the graph's own: an event recorded outside the
+        # capture may not be waited on there)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._lex_done is not None and not capturing:
             cur.wait_event(self._lex_done)
         if self._ws_lex is None or self._ws_lex.numel() < need:   # kept: no allocation per search
             self._ws_lex = torch.empty(need, dtype=torch.uint8, device=self.device)
         try:
             return self._bm25_call(L, qt, k, dc, qc, conjunctive, prune, dense_rows)
         finally:
-            if self._lex_done is None:
-                self._lex_done = torch.cuda.Event()
-            self._lex_done.record(cur)
+            if not capturing:
+                if self._lex_done is None:
+                    self._lex_done = torch.cuda.Event()
+                self._lex_done.record(cur)
 
     def _bm25_call(self, L, qt, k, dc, qc, conjunctive, prune, dense_rows):
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
