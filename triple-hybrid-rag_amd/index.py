@@ -45,33 +45,6 @@ class BatchResult:
     rescued: object = 0
 
 
-class StepGraph:
-    """One step of the batch pipeline captured as a hipGraph over STATIC buffers: ``fn`` (e.g.
-    ``lambda: index.retrieve_batch(embed_postproc(raw), terms, seeds)``) is run ``warmup`` times --
-    workspaces get allocated, the library's lazily read knobs are read -- and then captured;
-    ``replay()`` re-enqueues the whole kernel sequence, both streams of it, with ONE host call
-    (a step of a 125 K-row shard is ~20 kernels of 5..350 us: launched one by one from Python
-    the host is the bottleneck).  ``result`` is what ``fn`` returned inside the capture: its
-    tensors are rewritten by every replay.  New inputs go in by copying into the tensors ``fn``
-    read (``raw.copy_(...)``): the graph holds their addresses."""
-
-    def __init__(self, fn, warmup: int = 2):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.result = fn()
-
-    def replay(self):
-        self.graph.replay()
-        return self.result
-
-
 class GpuIndex:
     def __init__(self, device: Optional[torch.device] = None, doc_base: int = 0):
         if not torch.cuda.is_available():
@@ -336,20 +309,16 @@ class GpuIndex:
         # one, or the side stream of side_channels / GpuIndexClient's deferred RPC): the stream of
         # this call waits for the previous call's kernels before its memset touches the workspace
         cur = torch.cuda.current_stream(self.device)
-        # (inside a hipGraph capture the order is the graph's own: an event recorded outside the
-        # capture may not be waited on there)
-        capturing = torch.cuda.is_current_stream_capturing()
-        if self._lex_done is not None and not capturing:
+        if self._lex_done is not None:
             cur.wait_event(self._lex_done)
         if self._ws_lex is None or self._ws_lex.numel() < need:   # kept: no allocation per search
             self._ws_lex = torch.empty(need, dtype=torch.uint8, device=self.device)
         try:
             return self._bm25_call(L, qt, k, dc, qc, conjunctive, prune, dense_rows)
         finally:
-            if not capturing:
-                if self._lex_done is None:
-                    self._lex_done = torch.cuda.Event()
-                self._lex_done.record(cur)
+            if self._lex_done is None:
+                self._lex_done = torch.cuda.Event()
+            self._lex_done.record(cur)
 
     def _bm25_call(self, L, qt, k, dc, qc, conjunctive, prune, dense_rows):
         return N.bm25_topk(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
