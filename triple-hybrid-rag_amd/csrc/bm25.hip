@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 // deterministic list.
 constexpr int FILTER_THREADS = 1024;
 __global__ __launch_bounds__(FILTER_THREADS) void bm25_sweep_filter_kernel(
-    int32_t* __restrict__ ctl, int nq, int slice_major, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
+    int32_t* __restrict__ ctl, int nq, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
     const int32_t* __restrict__ q_item0, const double* __restrict__ q_dub,
     const unsigned long long* __restrict__ theta_glob, int32_t* __restrict__ slice_cnt,
     int32_t* __restrict__ sweep_items) {
@@ -1367,8 +1367,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void bm25_sweep_filter_kernel(
         const bool on = q - q0 < 64 ? ((live >> (q - q0)) & 1ull) != 0ull : sweeps(q);
         if (!on) continue;
         const int SA = q_SA[q], SB = q_S[q] - SA;   // (SB is the same for every query of a batch)
-        for (int s = 0; s < SB; ++s)
-            sweep_items[slice_major ? (int64_t)s * n_sw + rank : (int64_t)rank * SB + s] = item_of(q, SA + s);
+        for (int s = 0; s < SB; ++s) sweep_items[(int64_t)s * n_sw + rank] = item_of(q, SA + s);
         n_items = SB;
         ++rank;
     }
@@ -1986,11 +1985,9 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #ifdef BM_STAMPS
     hipMemsetAsync(ws + L.off_stamps, 0, sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap), st);
 #endif
-    static int small = -1, per_cu = -1, target_max = BM_TARGET0, use_imp = 1, use_dense = 1, walk_div = 64, fuse_div = 8;
+    static int small = -1, use_dense = 1, walk_div = 64, fuse_div = 8;
     if (small < 0) {
-        const char* ei = getenv("THR_BM25_IMPACT");   // 0: term / block bounds only (A/B knob)
-        use_imp = !(ei && ei[0] == '0');
-        ei = getenv("THR_BM25_DENSE");                // 0: every term through its postings (A/B knob)
+        const char* ei = getenv("THR_BM25_DENSE");    // 0: every term through its postings (A/B knob)
         use_dense = !(ei && ei[0] == '0');
         ei = getenv("THR_BM25_WALK_DIV");             // a term with rows may be walked when held by < 1/this of the docs
         if (ei && atoi(ei) > 0) walk_div = atoi(ei);
@@ -1998,20 +1995,16 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         if (ei && atoi(ei) >= 0) fuse_div = atoi(ei);
         const char* ev = getenv("THR_BM25_SHAPE");
         small = (ev && ev[0] == 's') ? 1 : (ev && ev[0] == 'h') ? 2 : 0;   // s(mall) / h(uge)
-        ev = getenv("THR_BM25_GRID");        // workgroups per CU of the persistent grid
-        per_cu = ev && atoi(ev) > 0 ? atoi(ev) : 0;
-        ev = getenv("THR_BM25_TARGET");      // postings per slice when the batch fills the grid
-        if (ev && atoi(ev) >= BM_TARGET_MIN) target_max = atoi(ev);
     }
     const bool big = small == 0, huge = small == 2;
     // persistent grid: as many workgroups as the chip holds at once (never more than items can exist)
-    int grid = bm_num_cus() * (per_cu ? per_cu : (huge ? 1 : big ? 2 : 4));
+    int grid = bm_num_cus() * (huge ? 1 : big ? 2 : 4);
     if (grid > L.cap) grid = L.cap;
-    const int32_t* dslot = (use_dense && use_imp) ? dense_slot : nullptr;
+    const int32_t* dslot = use_dense ? dense_slot : nullptr;
     int plan_blocks = (n_queries + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_blocks = plan_blocks > PLAN_MAX_BLOCKS ? PLAN_MAX_BLOCKS : plan_blocks;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(plan_blocks), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, target_max, walk_div, dslot, term_ub, n_docs, ctl,
+                       n_queries, max_terms, L.cap, conjunctive, grid, BM_TARGET0, walk_div, dslot, term_ub, n_docs, ctl,
                        q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
@@ -2033,7 +2026,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #define THR_BM25_LAUNCH(T, S, W, C, DP)                                                            \
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C, DP>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
-                       (term_ub && use_imp) ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
+                       term_ub ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
                        avgdl, k1, b,                                                                \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, n_queries,         \
                        dslot ? fuse_div : 0, ctl, q_nt, q_S,                                        \
@@ -2054,12 +2047,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         THR_BM25_LAUNCH_SHAPE(2);
         THR_BM25_LAUNCH_SHAPE(1);
         if ((rc = launch_status())) return rc;
-        static int slice_major = -1;
-        if (slice_major < 0) {
-            const char* eo = getenv("THR_BM25_SWEEP_ORDER");   // q(uery-major) / s(lice-major): A/B knob
-            slice_major = !(eo && eo[0] == 'q');
-        }
-        hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3(1), dim3(FILTER_THREADS), 0, st, ctl, n_queries, slice_major, q_S,
+        hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3(1), dim3(FILTER_THREADS), 0, st, ctl, n_queries, q_S,
                            q_SA, q_item0, q_dub, theta, slice_cnt, sweep_items);
         int wgrid = bm_num_cus() * 2;
         if (wgrid > L.cap) wgrid = L.cap;

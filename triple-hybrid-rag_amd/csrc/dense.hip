@@ -14,8 +14,8 @@
 //   K3 scan<MODE_FILTER>        THE dominant kernel: stream the corpus once per query tile,
 //                               emit (score, row) >= tau[q].  Default: dense_scan_f16qs (f16
 //                               MFMA over the normalised f16 copy, queries in registers);
-//                               dense_scan_f16 / dense_scan_mfma2 / the fp32 FMA scan are the
-//                               other flavours
+//                               dense_scan_f16 / dense_scan_mfma2 (dense_scan_mfma at dim 1024)
+//                               are the other flavours
 //   K4a select_band             per query: the band of candidates that can still reach the
 //                               top-k -> a shortlist of rows
 //   K4b rescore_rank            shortlist re-scored in float64 with sequential accumulation
@@ -29,8 +29,6 @@
 
 namespace thr {
 
-constexpr int SCAN_THREADS = 512;          // 8 waves share one LDS query tile
-constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int CHUNK = 256;                 // floats per wave-wide float4 load (1 KiB)
 constexpr int MODE_ALL = 0, MODE_FILTER = 1;
 constexpr int CAND_CAP = 16384;            // candidates kept per query between K3 and K4
@@ -45,237 +43,6 @@ struct Cand {
     uint32_t doc;
 };
 
-// ---------------------------------------------------------------------------
-// wave-transpose reduction: every lane holds V partial sums v[0..V); afterwards
-// lane l holds the 64-lane totals of elements (V/64)*l + j, j < V/64, in v[j].
-// ---------------------------------------------------------------------------
-// one butterfly level over lane bit M with N live values per lane (static indexing only:
-// a runtime-indexed register array would be demoted to scratch)
-template <int N, int M, int V>
-__device__ __forceinline__ void reduce_levels_shfl(float (&v)[V], int lane) {
-    const bool hi = (lane & M) != 0;
-#pragma unroll
-    for (int j = 0; j < N / 2; ++j) {
-        float keep = hi ? v[j + N / 2] : v[j];
-        float give = hi ? v[j] : v[j + N / 2];
-        v[j] = keep + __shfl_xor(give, M, WAVE);
-    }
-    if constexpr (M > 1) reduce_levels_shfl<N / 2, M / 2, V>(v, lane);
-}
-
-template <int V, bool SWAPS>
-__device__ __forceinline__ void wave_transpose_reduce(float (&v)[V], int lane) {
-    static_assert(V >= 64 && (V & (V - 1)) == 0, "V must be a power of two >= 64");
-    if constexpr (SWAPS) {
-        // lanes l / l+32: v_permlane32_swap exchanges the upper half of its first operand
-        // with the lower half of its second, so a+b afterwards is the pair sum of v[j] in
-        // the lower lane and of v[j+V/2] in the upper lane; v_permlane16_swap does the same
-        // between the odd and even 16-lane rows.
-#pragma unroll
-        for (int j = 0; j < V / 2; ++j) {
-            auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]),
-                                                      __float_as_uint(v[j + V / 2]), false, false);
-            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-        }
-#pragma unroll
-        for (int j = 0; j < V / 4; ++j) {
-            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]),
-                                                      __float_as_uint(v[j + V / 4]), false, false);
-            v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-        }
-        reduce_levels_shfl<V / 4, 8, V>(v, lane);
-    } else {
-        reduce_levels_shfl<V, 32, V>(v, lane);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// K1 / K3: the streaming scan.
-//   QT   queries per tile (LDS-resident, [QT][dim] floats)
-//   R    doc rows per wave per step (register blocking: each LDS query read feeds R rows)
-//   NCH  dim / 256
-// A wave owns R consecutive rows; lane l holds dims [256c + 4l, +4) of each row for
-// chunk c (one fully coalesced 1 KiB load per row and chunk), accumulates R*QT partial
-// dots, then the wave-transpose reduction leaves (R*QT)/64 finished dots per lane.
-// ---------------------------------------------------------------------------
-template <int QT, int R, int NCH, int MODE, bool SWAPS>
-__global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
-    const float* __restrict__ docs, const float* __restrict__ inv_norm, int64_t n_docs,
-    const float* __restrict__ queries, int n_queries,
-    int64_t n_groups,      // doc groups (of R rows) this launch visits
-    int64_t group_stride,  // actual group = visited index * group_stride
-    const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
-    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
-    constexpr int D = NCH * CHUNK;
-    constexpr int V = R * QT;
-    constexpr int NF = V / 64;  // finished values per lane
-    extern __shared__ float4 lds_q[];  // [QT][D/4], then SCAN_WAVES * WBUF staging slots
-
-    const int tile = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    // wave-uniform by construction; readfirstlane lets hipcc keep everything derived from it
-    // (group index, row bases, loop control) in SGPRs and scalar ALU
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    Cand* wbuf = reinterpret_cast<Cand*>(lds_q + QT * (D / 4)) + wave * WBUF;
-    int wcnt = 0;  // wave-uniform fill of wbuf
-    // Rows that pass the filter are staged in LDS and copied out in bulk: a returning global
-    // atomic per passing row would sit in the in-order vmcnt queue behind 12 KiB of prefetch
-    // and drain it, and any VMEM store left pending at the loop back-edge makes hipcc fall
-    // back to vmcnt(0) waits everywhere in the loop.
-    auto flush = [&]() {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&tile_cnt[tile], wcnt);
-        base = __shfl(base, 0, WAVE);
-        for (int i = lane; i < wcnt; i += WAVE)
-            if (base + i < tile_cap) tile_list[(int64_t)tile * tile_cap + base + i] = wbuf[i];
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing but loads pending afterwards
-        wcnt = 0;
-    };
-
-    // stage the query tile (rows past n_queries are zero)
-    for (int i = threadIdx.x; i < QT * (D / 4); i += SCAN_THREADS) {
-        const int q = tile * QT + i / (D / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < n_queries)
-            v = reinterpret_cast<const float4*>(queries)[(int64_t)q * (D / 4) + i % (D / 4)];
-        lds_q[i] = v;
-    }
-    __syncthreads();
-
-    // what this lane owns after the reduction: element e = NF*lane + j -> (row e/QT, query e%QT)
-    float my_tau[NF];
-    int my_q[NF], my_r[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        int e = NF * lane + j;
-        my_q[j] = e % QT;
-        my_r[j] = e / QT;
-        my_tau[j] = MODE == MODE_FILTER ? tau[tile * QT + my_q[j]] : 0.f;
-    }
-
-    const int64_t wave_id = (int64_t)blockIdx.x * SCAN_WAVES + wave;
-    const int64_t wave_stride = (int64_t)gridDim.x * SCAN_WAVES;
-    const float4* docs4 = reinterpret_cast<const float4*>(docs);
-
-    // The order of LDS reads, global loads and FMAs below is pinned with empty volatile
-    // asm statements: THR_PIN(x) makes x opaque at that point, so a load whose address is
-    // pinned cannot be hoisted above it and arithmetic feeding a pinned value cannot sink
-    // below it.  Left alone, hipcc clusters all ds_reads of a chunk ahead of the FMAs and
-    // spills the accumulators.
-#define THR_PIN(x) asm volatile("" : "+v"(x))
-    // d[c] holds chunk c of the R rows being computed; as soon as chunk c has been consumed
-    // the same registers are refilled with chunk c of the wave's NEXT group, so NCH-1 chunk
-    // stages (8 KiB per wave at dim 768) are always in flight and no register copies exist.
-    float4 d[NCH][R];
-    // Row bases are wave-uniform float4 offsets held in SGPRs (pinned as scalars: a pinned
-    // POINTER would lose its address space and load as flat_*); the lane adds its 16 bytes.
-#define THR_PIN_S(x) asm volatile("" : "+s"(x))
-    int64_t ptr[R];
-    auto set_ptrs = [&](int64_t g) {
-        int64_t row0 = g * group_stride * R;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int64_t row = row0 + r;
-            row = row < n_docs ? row : n_docs - 1;  // clamp: tail rows are masked at emission
-            ptr[r] = row * (D / 4);
-        }
-    };
-
-    int64_t g = wave_id;
-    if (g < n_groups) {
-        set_ptrs(g);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                THR_PIN_S(ptr[r]);  // same issue order as the steady state: exact vmcnt counts
-                d[c][r] = docs4[ptr[r] + c * (CHUNK / 4) + lane];
-            }
-    }
-    for (; g < n_groups; g += wave_stride) {
-        float acc[V];
-#pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] = 0.f;
-        // 1/||d|| of the rows this lane will emit, requested BEFORE the chunk loop so that it
-        // is the oldest outstanding load at emission time (vmcnt retires in order; a load
-        // issued after the prefetches would drain all of them)
-        const int64_t row0 = g * group_stride * R;
-        float inv[NF];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            int idx = my_r[j];
-            if (row0 + idx >= n_docs) idx = (int)(n_docs - 1 - row0);
-            THR_PIN(idx);
-            inv[j] = inv_norm[row0 + idx];
-        }
-        // The refill is unconditional (the wave's last group re-requests itself): a prefetch
-        // under a branch leaves two possible queue depths at every later wait and hipcc then
-        // waits for the shallower one, i.e. over-waits by a whole chunk stage.
-        set_ptrs(g + wave_stride < n_groups ? g + wave_stride : g);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            // query values run two LDS reads ahead of their FMAs
-            int qi = c * (CHUNK / 4) + lane;
-            THR_PIN(qi);
-            float4 q0 = lds_q[qi], q1 = lds_q[qi + (D / 4)];
-#pragma unroll
-            for (int q = 0; q < QT; ++q) {
-                const float4 qv = q0;
-                q0 = q1;
-                if (q + 2 < QT) {
-                    THR_PIN(qi);
-                    q1 = lds_q[qi + (q + 2) * (D / 4)];
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float a = acc[r * QT + q];
-                    a = __builtin_fmaf(d[c][r].x, qv.x, a);
-                    a = __builtin_fmaf(d[c][r].y, qv.y, a);
-                    a = __builtin_fmaf(d[c][r].z, qv.z, a);
-                    a = __builtin_fmaf(d[c][r].w, qv.w, a);
-                    acc[r * QT + q] = a;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) THR_PIN(acc[r * QT + q]);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                THR_PIN_S(ptr[r]);
-                d[c][r] = docs4[ptr[r] + c * (CHUNK / 4) + lane];
-            }
-        }
-#undef THR_PIN
-#undef THR_PIN_S
-        wave_transpose_reduce<V, SWAPS>(acc, lane);
-
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int64_t row = row0 + my_r[j];
-            const bool ok = row < n_docs;
-            const float sc = acc[j] * inv[j];
-            if constexpr (MODE == MODE_ALL) {
-                int q = tile * QT + my_q[j];
-                sample_scores[(int64_t)q * sample_ld + g * R + my_r[j]] =
-                    (ok && inv[j] > 0.f) ? sc : -INFINITY;
-            } else {
-                const bool pass = ok && inv[j] > 0.f && sc >= my_tau[j];
-                const uint64_t m = __ballot(pass);
-                if (m) {
-                    const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pass) wbuf[pos] = Cand{sc, ((uint32_t)my_q[j] << ROW_BITS) | (uint32_t)row};
-                    wcnt += __popcll(m);
-                }
-            }
-        }
-        if constexpr (MODE == MODE_FILTER) {
-            if (wcnt > WBUF - NF * WAVE) flush();
-        }
-    }
-    if constexpr (MODE == MODE_FILTER) {
-        if (wcnt > 0) flush();
-    }
-}
-
 }  // namespace thr
 // ---------------------------------------------------------------------------
 // Block -> (row slice, query tile) for the MFMA scans.
@@ -283,25 +50,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void dense_scan(
 // workgroups are dealt round-robin over the XCDs (b and b+8 share one), and a 1-D grid of
 // 8 * m * n_qtiles blocks is decoded so that the blocks resident together on one XCD are the
 // n_qtiles query tiles of the SAME row slice.  They walk identical addresses in step: the
-// first one to ask for a line pulls it from HBM, the others hit it in that XCD's L2.  A 2-D
-// launch (gridDim.y > 1) keeps the plain (slice = x, query tile = y) layout.  Placement is a
-// speed matter only: any dispatch order gives the same result.
+// first one to ask for a line pulls it from HBM, the others hit it in that XCD's L2.
+// Placement is a speed matter only: any dispatch order gives the same result.
 // ---------------------------------------------------------------------------
 struct ScanSlot {
     int qtile, slice, nslices;
 };
 __device__ __forceinline__ ScanSlot scan_slot(int n_qtiles) {
     ScanSlot s;
-    if (gridDim.y > 1) {
-        s.qtile = blockIdx.y;
-        s.slice = blockIdx.x;
-        s.nslices = gridDim.x;
-    } else {
-        const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-        s.qtile = j % n_qtiles;
-        s.slice = xcd + 8 * (j / n_qtiles);
-        s.nslices = gridDim.x / n_qtiles;
-    }
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    s.qtile = j % n_qtiles;
+    s.slice = xcd + 8 * (j / n_qtiles);
+    s.nslices = gridDim.x / n_qtiles;
     return s;
 }
 
@@ -1329,38 +1089,6 @@ struct DensePlan {
     size_t off_tau, off_qerr, off_cnt, off_tcnt, off_cand, off_tlist, off_sample, off_qfrag, total;
 };
 
-constexpr int R_DEFAULT = 4;
-
-// queries per tile pass: 32 by default, THR_DENSE_QT=16 selects the half-size tile
-static int query_tile() {
-    static int qt = 0;
-    if (!qt) {
-        const char* e = getenv("THR_DENSE_QT");
-        qt = (e && atoi(e) == 16) ? 16 : 32;
-    }
-    return qt;
-}
-
-// THR_DENSE_IMPL=valu selects the VALU scan (dense_scan<>); default is the fp32-MFMA scan
-static bool use_mfma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("THR_DENSE_IMPL");
-        v = (e && e[0] == 'v') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-// THR_DENSE_MFMA=1 selects the fragment-load MFMA scan, default 2 = LDS-transpose variant
-static int mfma_version() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("THR_DENSE_MFMA");
-        v = (e && atoi(e) == 1) ? 1 : 2;
-    }
-    return v;
-}
-
 constexpr int KIND_F32 = 0, KIND_F16 = 1;
 // in-flight-rounding f16 scan (dense_scan_f16): query sub-tiles of 32 per pass -- 2 (64 queries,
 // 96 KiB of LDS at dim 768) when the tile fits next to the transpose tiles, else 1
@@ -1414,8 +1142,8 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     p.nq = (kind == KIND_F16 && !p.packed) ? f16_pick_nq(dim) : 1;
     p.row_bits = (kind == KIND_F16 && !p.qreg) ? ROW_BITS_F16 : ROW_BITS;
     p.qtile = p.qreg ? 32 * qreg_waves(dim)
-              : kind == KIND_F16 ? 32 * p.nq : (use_mfma() ? MF_QT : query_tile());
-    p.unit = (kind == KIND_F16 || use_mfma()) ? MF_ROWS : R_DEFAULT;
+              : kind == KIND_F16 ? 32 * p.nq : MF_QT;
+    p.unit = MF_ROWS;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
     p.qpad = p.ntiles * p.qtile;
     const int64_t groups = (n_docs + p.unit - 1) / p.unit;
@@ -1483,23 +1211,10 @@ static int num_cus() {
 
 // Grid of an MFMA scan (see scan_slot): 1-D, 8 * m * n_qtiles blocks, one block per CU.  m is
 // chosen for the fullest last round of blocks, the smallest such m first (fewer, longer row
-// slices; at 32 query tiles m = 1 and the whole launch is a single round).  THR_DENSE_MAP=grid
-// restores the plain 2-D launch (x = row slice, y = query tile) for comparison.
+// slices; at 32 query tiles m = 1 and the whole launch is a single round).
 static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_rows,
                       int blocks_per_cu = 1, int m_cap = 64) {
-    static int plain = -1;
-    if (plain < 0) {
-        const char* e = getenv("THR_DENSE_MAP");
-        plain = (e && e[0] == 'g') ? 1 : 0;
-    }
     const int cus = num_cus() * blocks_per_cu;   // block slots
-    if (plain) {
-        int64_t blocks = (n_row_tiles + waves - 1) / waves;
-        if (blocks > cus) blocks = cus;
-        if (blocks < 1) blocks = 1;
-        *shared_rows = false;
-        return dim3((unsigned)blocks, (unsigned)ntiles);
-    }
     int64_t m_max = n_row_tiles / (8 * (int64_t)waves);  // every wave gets at least one row tile
     if (m_max < 1) m_max = 1;
     if (m_max > m_cap) m_max = m_cap;
@@ -1519,62 +1234,15 @@ static dim3 scan_grid(int ntiles, int64_t n_row_tiles, int waves, bool* shared_r
 }
 
 // row loads: non-temporal when no other query tile will ask for the same lines, plain when the
-// query tiles of a slice share them through L2.  THR_DENSE_NT=0|1 forces one flavour.
-static bool scan_nt(bool shared_rows) {
-    static int nt = -2;
-    if (nt == -2) {
-        const char* e = getenv("THR_DENSE_NT");
-        nt = e ? (e[0] == '0' ? 0 : 1) : -1;
-    }
-    return nt < 0 ? !shared_rows : nt == 1;
-}
-
-template <int MODE>
-static int launch_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
-                       const float* queries, int n_queries, int ntiles, int64_t n_groups,
-                       int64_t group_stride, const float* tau, int* tile_cnt, Cand* tile_list,
-                       int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    constexpr int R = R_DEFAULT;
-    const int qt = query_tile();
-    const size_t lds = sizeof(float) * qt * (size_t)dim + sizeof(Cand) * SCAN_WAVES * WBUF;
-    int64_t waves = n_groups;
-    int64_t blocks = (waves + SCAN_WAVES - 1) / SCAN_WAVES;
-    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;  // LDS-limited residency
-    if (blocks > (int64_t)num_cus() * per_cu) blocks = (int64_t)num_cus() * per_cu;
-    if (blocks < 1) blocks = 1;
-    dim3 grid((unsigned)blocks, (unsigned)ntiles);
-#define THR_SCAN_LAUNCH(QT, NCH)                                                                  \
-    {                                                                                             \
-        auto kern = dense_scan<QT, R, NCH, MODE, true>;                                           \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return (int)e;                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, docs, inv_norm, n_docs,       \
-                           queries, n_queries, n_groups, group_stride, tau, tile_cnt, tile_list,  \
-                           tile_cap, sample, sample_ld);                                          \
-    }
-#define THR_SCAN_CASE(NCH)                                   \
-    case NCH:                                                \
-        if (qt == 16) THR_SCAN_LAUNCH(16, NCH) else THR_SCAN_LAUNCH(32, NCH) \
-        break;
-    switch (dim / CHUNK) {
-        THR_SCAN_CASE(1)
-        THR_SCAN_CASE(2)
-        THR_SCAN_CASE(3)
-        THR_SCAN_CASE(4)
-        default:
-            return THR_ERR_UNSUPPORTED;
-    }
-#undef THR_SCAN_LAUNCH
-#undef THR_SCAN_CASE
-    return launch_status();
-}
+// query tiles of a slice share them through L2
+static bool scan_nt(bool shared_rows) { return !shared_rows; }
 
 template <int MODE>
 static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
                             const float* queries, int n_queries, int ntiles, int64_t n_row_tiles,
                             int64_t tile_stride, const float* tau, int* tile_cnt, Cand* tile_list,
-                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
+                            int tile_cap, float* sample, int64_t sample_ld, hipStream_t st,
+                            const int32_t* doc_coll = nullptr, const int32_t* query_coll = nullptr) {
     const size_t lds1 = sizeof(float) * MF_QT * (size_t)dim + sizeof(Cand) * MF_WAVES * WBUF;
     auto lds2_for = [&](int nw) {
         return sizeof(float) * MF_QT * (size_t)dim + (sizeof(Cand) * WBUF + sizeof(float4) * MF2_STAGE_F4) * nw;
@@ -1583,7 +1251,7 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
     // 768.  At dim 1024 only 4 waves (one per SIMD) would fit, and that measured slower than
     // the fragment-load variant with 8 waves (4.30 vs 4.93 TB/s), which therefore runs there.
     int nw = 0;
-    if (mfma_version() == 2 && dim % 128 == 0 && dim >= 256)
+    if (dim % 128 == 0 && dim >= 256)
         nw = lds2_for(8) <= 160 * 1024 ? 8 : 0;
     const bool v2 = nw != 0;
     const size_t lds = v2 ? lds2_for(nw) : lds1;
@@ -1599,7 +1267,7 @@ static int launch_scan_mfma(int dim, const float* docs, const float* inv_norm, i
         if (e != hipSuccess) return (int)e;                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(THREADS), lds, st, docs, inv_norm, n_docs, queries,   \
                            n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list,         \
-                           tile_cap, sample, sample_ld);                                          \
+                           tile_cap, sample, sample_ld, doc_coll, query_coll);                    \
     }
 #define THR_MF_CASE(D8)                                                                           \
     case D8:                                                                                      \
@@ -1626,7 +1294,8 @@ static int launch_scan_f16(int dim, int nq, const float* rows32, const float* in
                            int64_t n_docs, const float* queries, int n_queries, int ntiles,
                            int64_t n_row_tiles, int64_t tile_stride, const float* tau, int* tile_cnt,
                            Cand* tile_list, int tile_cap, float* sample, int64_t sample_ld,
-                           hipStream_t st) {
+                           hipStream_t st, const int32_t* doc_coll = nullptr,
+                           const int32_t* query_coll = nullptr) {
     const size_t lds = f16_lds_bytes(dim, nq);
     THR_RETURN_IF(lds > 160 * 1024, THR_ERR_UNSUPPORTED);
     bool shared_rows = false;
@@ -1640,7 +1309,7 @@ static int launch_scan_f16(int dim, int nq, const float* rows32, const float* in
         if (e != hipSuccess) return (int)e;                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(H_THREADS), lds, st, rows32, inv_norm, n_docs,        \
                            queries, n_queries, n_row_tiles, tile_stride, tau, tile_cnt, tile_list, \
-                           tile_cap, sample, sample_ld);                                          \
+                           tile_cap, sample, sample_ld, doc_coll, query_coll);                    \
     }
 #define THR_H_INLINE(DIM, NQV)                                                                    \
     {                                                                                             \
@@ -1734,24 +1403,10 @@ static int launch_pack_queries(int dim, const float* queries, int n_queries, int
     return launch_status();
 }
 
-template <int MODE>
-static int launch_any_scan(int dim, const float* docs, const float* inv_norm, int64_t n_docs,
-                           const float* queries, int n_queries, int ntiles, int64_t n_units,
-                           int64_t unit_stride, const float* tau, int* tile_cnt, Cand* tile_list,
-                           int tile_cap, float* sample, int64_t sample_ld, hipStream_t st) {
-    if (use_mfma())
-        return launch_scan_mfma<MODE>(dim, docs, inv_norm, n_docs, queries, n_queries, ntiles,
-                                      n_units, unit_stride, tau, tile_cnt, tile_list, tile_cap,
-                                      sample, sample_ld, st);
-    return launch_scan<MODE>(dim, docs, inv_norm, n_docs, queries, n_queries, ntiles, n_units,
-                             unit_stride, tau, tile_cnt, tile_list, tile_cap, sample, sample_ld, st);
-}
-
-// fp32 error bound of the scan, relative to ||q||*||d||, in units of 2^-24:
-//   VALU: dim/64 chained FMAs per lane + 6 tree adds + 2 roundings; MFMA: a dim-long fma chain
+// fp32 error bound of the MFMA scan, relative to ||q||*||d||, in units of 2^-24: a dim-long fma chain
 static double scan_eps(int dim) {
     const double u = 5.9604644775390625e-08;
-    return use_mfma() ? ((double)dim + 16.0) * u : ((double)dim / 16.0 + 16.0) * u;
+    return ((double)dim + 16.0) * u;
 }
 
 }  // namespace thr
@@ -1796,13 +1451,13 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                                                    nullptr, nullptr, 0, smp, ld, st)
                        : launch_scan_f16<MODE_FILTER>(dim, p.nq, docs, inv_norm, n_docs, queries,
                                                       n_queries, p.ntiles, units, stride, tau, tcnt,
-                                                      tlist, p.tile_cap, nullptr, 0, st);
-        return all ? launch_any_scan<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
+                                                      tlist, p.tile_cap, nullptr, 0, st, doc_coll, query_coll);
+        return all ? launch_scan_mfma<MODE_ALL>(dim, docs, inv_norm, n_docs, queries, n_queries,
                                                p.ntiles, units, stride, nullptr, nullptr, nullptr,
                                                0, smp, ld, st)
-                   : launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries,
+                   : launch_scan_mfma<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries,
                                                   p.ntiles, units, stride, tau, tcnt, tlist,
-                                                  p.tile_cap, nullptr, 0, st);
+                                                  p.tile_cap, nullptr, 0, st, doc_coll, query_coll);
     };
     hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
     if (e != hipSuccess) return (int)e;
@@ -1966,7 +1621,7 @@ extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, in
     // rate); the tile counters are reset so the lists never overflow across repeats
     hipError_t e = hipMemsetAsync(ws + p.off_tcnt, 0, sizeof(int) * p.ntiles, st);
     if (e != hipSuccess) return (int)e;
-    return launch_any_scan<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
+    return launch_scan_mfma<MODE_FILTER>(dim, docs, inv_norm, n_docs, queries, n_queries, p.ntiles,
                                         p.groups, 1, (const float*)(ws + p.off_tau),
                                         (int*)(ws + p.off_tcnt), (Cand*)(ws + p.off_tlist),
                                         p.tile_cap, nullptr, 0, st);

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     const void* __restrict__ docs16, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
     const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
-    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
+    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll = nullptr, const int32_t* __restrict__ query_coll = nullptr) {
     constexpr int QT = 32 * NQ;
     constexpr int CPR = DIM / 8;   // 16-byte chunks (8 halves) per row
     constexpr int GPR = DIM / 4;   // 16-byte chunks per float32 row in global memory
@@ -96,9 +97,13 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
     __syncthreads();
 
     float my_tau[NQ];
+    int my_qc[NQ];   // collection filter of the lane's queries (-1: none), applied as rows pass tau
 #pragma unroll
-    for (int s = 0; s < NQ; ++s)
+    for (int s = 0; s < NQ; ++s) {
         my_tau[s] = MODE == MODE_FILTER ? tau[qtile * QT + 32 * s + r] : 0.f;
+        my_qc[s] = (MODE == MODE_FILTER && query_coll && qtile * QT + 32 * s + r < n_queries)
+                       ? query_coll[qtile * QT + 32 * s + r] : -1;
+    }
     const int64_t wave_id = (int64_t)slot.slice * H_WAVES + wave;
     const int64_t wave_stride = (int64_t)slot.nslices * H_WAVES;
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs16);
@@ -244,7 +249,8 @@ __global__ __launch_bounds__(H_THREADS) void dense_scan_f16(
                 if constexpr (MODE == MODE_ALL) {
                     (void)ok; (void)sc;
                 } else {
-                    const bool pass = ok && inv > 0.f && sc >= my_tau[s];
+                    bool pass = ok && inv > 0.f && sc >= my_tau[s];
+                    if (pass && my_qc[s] != -1 && doc_coll[row0 + row] != my_qc[s]) pass = false;
                     const uint64_t m = __ballot(pass);
                     if (m) {
                         const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
     int64_t n_tiles,      // row tiles (of 32 rows) this launch visits
     int64_t tile_stride,  // actual row tile = visited index * tile_stride
     const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
-    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
+    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll = nullptr, const int32_t* __restrict__ query_coll = nullptr) {
     constexpr int D = D8 * 8;
     constexpr int CPR = D / 4;  // 16-byte chunks per row
     extern __shared__ float4 lds_q[];  // [MF_QT][CPR] swizzled, then MF_WAVES * WBUF staging slots
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
     __syncthreads();
 
     const float my_tau = MODE == MODE_FILTER ? tau[qtile * MF_QT + r] : 0.f;
+    // collection filter of this lane's query (-1: none), applied as rows pass tau: tau was taken
+    // from the sample rows of THAT collection, so without the filter here a collection of 1/c of
+    // the corpus lets c times the aimed candidates through and overflows the tile list
+    const int my_qc = (MODE == MODE_FILTER && query_coll && qtile * MF_QT + r < n_queries)
+                          ? query_coll[qtile * MF_QT + r] : -1;
     const int64_t wave_id = (int64_t)slot.slice * MF_WAVES + wave;
     const int64_t wave_stride = (int64_t)slot.nslices * MF_WAVES;
     const float4* docs4 = reinterpret_cast<const float4*>(docs);
@@ -163,7 +169,8 @@ __global__ __launch_bounds__(MF_THREADS) void dense_scan_mfma(
                 sample_scores[(int64_t)qg * sample_ld + t * MF_ROWS + row] =
                     (ok && inv > 0.f) ? sc : -INFINITY;
             } else {
-                const bool pass = ok && inv > 0.f && sc >= my_tau;
+                bool pass = ok && inv > 0.f && sc >= my_tau;
+                if (pass && my_qc != -1 && doc_coll[row0 + row] != my_qc) pass = false;
                 const uint64_t m = __ballot(pass);
                 if (m) {
                     const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
@@ -211,7 +218,8 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
     const float* __restrict__ docs, const float* __restrict__ inv_norm, int64_t n_docs,
     const float* __restrict__ queries, int n_queries, int64_t n_tiles, int64_t tile_stride,
     const float* __restrict__ tau, int* __restrict__ tile_cnt, Cand* __restrict__ tile_list,
-    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld) {
+    int tile_cap, float* __restrict__ sample_scores, int64_t sample_ld,
+    const int32_t* __restrict__ doc_coll = nullptr, const int32_t* __restrict__ query_coll = nullptr) {
     constexpr int D = D8 * 8;
     constexpr int CPR = D / 4;
     constexpr int NG = D / 128;  // groups of 4 stages of 32 dims
@@ -249,6 +257,11 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
     __syncthreads();
 
     const float my_tau = MODE == MODE_FILTER ? tau[qtile * MF_QT + r] : 0.f;
+    // collection filter of this lane's query (-1: none), applied as rows pass tau: tau was taken
+    // from the sample rows of THAT collection, so without the filter here a collection of 1/c of
+    // the corpus lets c times the aimed candidates through and overflows the tile list
+    const int my_qc = (MODE == MODE_FILTER && query_coll && qtile * MF_QT + r < n_queries)
+                          ? query_coll[qtile * MF_QT + r] : -1;
     const int64_t wave_id = (int64_t)slot.slice * NW + wave;
     const int64_t wave_stride = (int64_t)slot.nslices * NW;
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
@@ -392,7 +405,8 @@ __global__ __launch_bounds__(NW * WAVE) void dense_scan_mfma2(
                 const float inv = __shfl(my_inv, row, WAVE);
                 const bool ok = row0 + row < n_docs;
                 const float sc = acc[i] * inv;
-                const bool pass = ok && inv > 0.f && sc >= my_tau;
+                bool pass = ok && inv > 0.f && sc >= my_tau;
+                if (pass && my_qc != -1 && doc_coll[row0 + row] != my_qc) pass = false;
                 const uint64_t m = __ballot(pass);
                 if (m) {
                     const int pos = wcnt + __popcll(m & ((1ull << lane) - 1ull));
