@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 7
+#define THR_ABI_VERSION 8
 
 typedef void *thr_stream_t;
 
@@ -183,6 +183,25 @@ int thr_dense_scan_stamps_f16(const uint16_t *docs16, int64_t n_docs, int dim, i
 int thr_dense_scan_probe(const float *docs, const float *inv_norm, int64_t n_docs, int dim,
                          const float *queries, int n_queries, void *workspace,
                          size_t workspace_bytes, thr_stream_t stream);
+
+/* f1  index build (the step before the path): the inverted index from tokenised rows, on the
+ * device.  The reference leaves this to PostgreSQL -- rag_child_chunks rows go in
+ * (src/voice_agent/rag2/ingest.py:361-470) and the `tsv` generated column + GIN index
+ * (database/migrations/20260114_rag2_schema.sql:146-148, 171-172) become the posting lists.
+ * ``doc`` / ``term`` / ``tf`` [n_pairs]: one entry per distinct (doc, term) of a chunk, or one per
+ * token occurrence with tf == NULL (every entry counts 1) -- entries that repeat add up; entries
+ * with doc outside [0, n_docs), term outside [0, n_vocab) or tf <= 0 are dropped.  Outputs:
+ * rowptr [V + 1], post_doc / post_tf [n_pairs] of which the first *nnz_out are written (doc
+ * ascending within a term), doclen [n_docs] = the docs' summed term frequencies (entries whose term
+ * is outside the vocabulary still count: they are tokens of the chunk), df [V] = postings
+ * per term of THIS shard (all-reduce it over the shards for the global idf), *nnz_out (device
+ * memory).  No host round trip inside; ``workspace`` >= thr_lexical_build_workspace_bytes(). */
+size_t thr_lexical_build_workspace_bytes(int64_t n_pairs, int64_t n_vocab);
+int thr_lexical_build(const int32_t *doc, const int32_t *term, const int32_t *tf /* or NULL */,
+                      int64_t n_pairs, int64_t n_docs, int64_t n_vocab, int64_t *rowptr,
+                      int32_t *post_doc, int32_t *post_tf, float *doclen, int64_t *df,
+                      int64_t *nnz_out, void *workspace, size_t workspace_bytes,
+                      thr_stream_t stream);
 
 /* a3  lexical channel: Okapi BM25 (k1, b) top-k over a CSR inverted index,
  * OR semantics, float64 accumulation in query-term order.

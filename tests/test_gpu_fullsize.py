@@ -60,11 +60,29 @@ def test_config2_1m_dense_bm25_rrf(T):
     d_, t_, f_ = synth.lexical_rows(0, n, n)
     v = synth.vocab_size(n)
     csr = synth.build_lexical_csr(d_, t_, f_, n, v)
-    del d_, t_, f_
     idf = O.bm25_idf(n, csr.df_local)
     avgdl = csr.sum_dl_local / n
     qt = mixed_lexical_queries(synth, nq, csr.df_local, n)
-    idx = T.GpuIndex().set_dense(x).set_lexical(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl)
+    # SURVEY 8f.1 at full size: the index is BUILT ON THE DEVICE from the 32M (doc, term, tf) rows
+    # (thr_lexical_build) -- rows to a searchable lexical index, bounds / impacts / dense-term rows
+    # included, in well under a minute, its arrays synth.build_lexical_csr's
+    import time
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(len(d_))
+    rows = [dev(a[perm].astype(np.int32)) for a in (d_, t_, f_)]
+    del d_, t_, f_, perm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx = T.GpuIndex().set_dense(x).set_lexical_rows(*rows, v, n_docs=n)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    assert build_s < 60.0, build_s
+    del rows
+    L = idx.lex
+    for got, want in ((L["rowptr"], csr.rowptr), (L["post_doc"], csr.post_doc), (L["post_tf"], csr.post_tf),
+                      (L["doclen"], csr.doclen), (L["idf"], idf)):
+        assert np.array_equal(got.cpu().numpy(), want)
+    assert L["avgdl"] == avgdl
     # the index's norms are the oracle's, bit for bit, on all 1M rows (the oracle below gets its own)
     dn = CO.doc_norms(x)
     assert np.array_equal(idx.dnorm.cpu().numpy(), dn)

@@ -843,6 +843,92 @@ def test_triple_hybrid_pipeline_fused_top10(T):
             assert [f100[j] for j in order] == list(ids3[i])
 
 
+def test_lexical_index_built_on_the_device(T, tmp_path):
+    """SURVEY 8f.1 at scale: thr_lexical_build turns tokenised rows into the CSR on the GPU --
+    arrays equal to the host builders' (synth.build_lexical_csr for (doc, term, tf) rows,
+    index_build.build_lexical for texts), whatever the order of the rows, with repeated pairs
+    adding up and out-of-range entries dropped; ``save(gpu_index=...)`` carries what set-up computed
+    on the device and ``load().to_gpu()`` searches with it, not recomputing any of it."""
+    import time
+    from triple_hybrid_rag_amd import index_build as IB
+    from triple_hybrid_rag_amd import synth
+    n = 200_000
+    v = synth.vocab_size(n)
+    doc, term, tf = synth.lexical_rows(0, n, n)
+    csr = synth.build_lexical_csr(doc, term, tf, n, v)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(doc))
+    # shuffled rows + junk the build must drop (doc / term out of range, tf <= 0) + a pair split in two
+    d2 = np.concatenate([doc[perm], [n, -1, 5, 7, 7]]).astype(np.int32)
+    t2 = np.concatenate([term[perm], [3, 3, v, 11, 11]]).astype(np.int32)
+    f2 = np.concatenate([tf[perm], [1, 1, 1, 2, 3]]).astype(np.int32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rowptr, pd_, ptf, dl, df = T._native.lexical_build(dev(d2), dev(t2), dev(f2), n, v)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    # (doc 7 may already hold term 11: the reference CSR adds the extra 5 the same way)
+    e_doc, e_term, e_tf = np.concatenate([doc, [7]]), np.concatenate([term, [11]]), np.concatenate([tf, [5]])
+    key = e_term.astype(np.int64) << 32 | e_doc
+    uk, inv = np.unique(key, return_inverse=True)
+    e_sum = np.bincount(inv, weights=e_tf).astype(np.int32)
+    assert np.array_equal(pd_.cpu().numpy(), (uk & 0xFFFFFFFF).astype(np.int32)) and np.array_equal(ptf.cpu().numpy(), e_sum)
+    assert np.array_equal(df.cpu().numpy(), np.bincount((uk >> 32).astype(np.int64), minlength=v))
+    assert np.array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(df.cpu().numpy())]))
+    dl_exp = np.bincount(e_doc, weights=e_tf, minlength=n).astype(np.float32)
+    dl_exp[5] += 1                                          # (term out of range: still a token of chunk 5)
+    assert np.array_equal(dl.cpu().numpy(), dl_exp) and build_s < 5.0
+    # the clean rows: exactly synth.build_lexical_csr's arrays, and a searchable index
+    idx = T.GpuIndex()
+    idx.set_lexical_rows(dev(doc[perm].astype(np.int32)), dev(term[perm].astype(np.int32)), dev(tf[perm].astype(np.int32)), v, n_docs=n)
+    L = idx.lex
+    for got, want in ((L["rowptr"], csr.rowptr), (L["post_doc"], csr.post_doc), (L["post_tf"], csr.post_tf),
+                      (L["doclen"], csr.doclen), (idx.df_local, csr.df_local)):
+        assert np.array_equal(got.cpu().numpy(), want)
+    idf = O.bm25_idf(n, csr.df_local)
+    assert np.array_equal(L["idf"].cpu().numpy(), idf) and L["avgdl"] == csr.sum_dl_local / n
+    qt = synth.lexical_queries(16, csr.df_local, 4)
+    S, I, cnt = idx.bm25_search(dev(qt), 50)
+    Se, Ie = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, csr.sum_dl_local / n, qt, n, 50)
+    assert_topk_equal(S, I, cnt, Se, Ie, [len(s_) for s_ in Se], "device-built index")
+    # texts: one entry per token occurrence (tf = None), against the host builder
+    words = [f"w{i}" for i in range(300)]
+    texts = [" ".join(words[int(t_)] for t_ in rng.integers(0, 300, int(rng.integers(0, 30)))) for _ in range(5000)]
+    vocab_h, rp_h, pd_h, tf_h, dl_h, idf_h, avg_h = IB.build_lexical(texts)
+    vocab_d, d_tok, t_tok = IB.lexical_rows(texts)
+    assert vocab_d == vocab_h
+    rp_d, pd_d, tf_d, dl_d, df_d = T._native.lexical_build(dev(d_tok), dev(t_tok), None, len(texts), len(vocab_d))
+    for got, want in ((rp_d, rp_h), (pd_d, pd_h), (tf_d, tf_h), (dl_d, dl_h)):
+        assert np.array_equal(got.cpu().numpy(), want)
+    # a saved index carries the device-side set-up; a loaded one searches without recomputing it
+    x, _ = rand_docs(5000, 768, 8)
+    children = [{"id": f"c{i}", "parent_id": f"p{i // 4}", "document_id": "d", "text": texts[i], "page": 1,
+                 "modality": "text", "embedding_1024": x[i].tolist()} for i in range(5000)]
+    hi = IB.from_rows(children, device=True)
+    hi_host = IB.from_rows(children)
+    for name in ("rowptr", "post_doc", "post_tf", "doclen", "idf"):
+        assert np.array_equal(getattr(hi, name), getattr(hi_host, name)), name
+    assert hi.avgdl == hi_host.avgdl and hi.store.vocab == hi_host.store.vocab
+    g = hi.to_gpu()
+    IB.save(hi, str(tmp_path / "idx"), gpu_index=g)
+    back = IB.load(str(tmp_path / "idx"))
+    assert back.derived["f16_layout"] == T._native.dense_f16_layout(768) and back.store.texts[17] == texts[17]
+    assert back.store.child_ids == [f"c{i}" for i in range(5000)] and back.store.row_index("c4999") == 4999
+    orig = (T._native.bm25_bounds, T._native.bm25_dense_terms, T._native.dense_quantize_f16)
+
+    def boom(*a, **k):
+        raise AssertionError("a loaded index recomputed what was saved with it")
+    T._native.bm25_bounds = T._native.bm25_dense_terms = T._native.dense_quantize_f16 = boom
+    try:
+        g2 = back.to_gpu()
+    finally:
+        T._native.bm25_bounds, T._native.bm25_dense_terms, T._native.dense_quantize_f16 = orig
+    q = x[:8] + 0.3 * rng.standard_normal((8, 768)).astype(np.float32)
+    qt = np.array([[vocab_h[words[int(t_)]] for t_ in rng.integers(0, 300, 3)] for _ in range(8)], dtype=np.int32)
+    r1, r2 = g.retrieve_batch(dev(q), dev(qt), top_k=10), g2.retrieve_batch(dev(q), dev(qt), top_k=10)
+    assert torch.equal(r1.ids, r2.ids) and torch.equal(r1.scores, r2.scores)
+
+
 def test_index_build_rows_through_the_kernels(T, tmp_path):
     """reference-shaped table rows (rag_child_chunks / rag_parent_chunks / rag_entities /
     rag_relations / rag_entity_mentions) -> index_build.from_rows -> save / load -> to_gpu(), and

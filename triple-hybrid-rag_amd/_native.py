@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -59,6 +59,8 @@ _SIGNATURES = {
                                   _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
+    "thr_lexical_build_workspace_bytes": (_sz, [_i64, _i64]),
+    "thr_lexical_build": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_bm25_block_count": (_sz, [_i64]),
     "thr_bm25_bounds": (_i32, [_vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp, _vp]),
     "thr_bm25_workspace_bytes": (_sz, [_i32, _i32, _i32]),
@@ -302,6 +304,14 @@ def dense_quantize_f16(docs: torch.Tensor, keep_copy: bool = True):
     return d16, float(err.item())
 
 
+def dense_f16_layout(dim: int) -> str:
+    """Tag of the fragment-major layout thr_dense_quantize_f16 writes in this process: the
+    register image of the MFMA shape the copy scan runs with (16x16x32, or 32x32x16 under the
+    A/B knob THR_DENSE_MFMA=32, which the library reads the same way).  A saved float16 image is
+    reused only under the tag it was written with."""
+    return f"fragment-major/mfma{32 if os.environ.get('THR_DENSE_MFMA') == '32' else 16}/dim{dim}"
+
+
 def dense_f16_workspace_bytes(n_docs: int, dim: int, n_queries: int, kprime: int) -> int:
     return int(load().thr_dense_f16_workspace_bytes(n_docs, dim, n_queries, kprime))
 
@@ -363,6 +373,38 @@ def dense_scan_stamps_f16(docs16, n_docs: int, queries_n: int, workspace: torch.
     _check(load().thr_dense_scan_stamps_f16(ph, n_docs, d, queries_n, pw, nbytes, out.data_ptr(),
                                             C.byref(nw), _stream()), "thr_dense_scan_stamps_f16")
     return out
+
+
+# --------------------------------------------------------------------- f1
+def lexical_build(doc: torch.Tensor, term: torch.Tensor, tf: Optional[torch.Tensor], n_docs: int,
+                  n_vocab: int):
+    """Tokenised rows on the device -> (rowptr i64 [V+1], post_doc i32 [nnz], post_tf i32 [nnz],
+    doclen f32 [n_docs], df i64 [V]): the CSR inverted index of this shard.  ``tf`` None: one
+    entry per token occurrence.  One host read-back at the end (the number of postings, to cut
+    the posting arrays to size)."""
+    pdoc = _dev(doc, torch.int32, "doc", 1)
+    pterm = _dev(term, torch.int32, "term", 1)
+    ptf = _dev(tf, torch.int32, "tf", 1) if tf is not None else None
+    n = doc.shape[0]
+    if term.shape[0] != n or (tf is not None and tf.shape[0] != n):
+        raise NativeError("lexical_build: doc / term / tf lengths differ")
+    dev = doc.device
+    rowptr = torch.empty(n_vocab + 1, dtype=torch.int64, device=dev)
+    post_doc = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    post_tf = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    doclen = torch.empty(n_docs, dtype=torch.float32, device=dev)
+    df = torch.empty(n_vocab, dtype=torch.int64, device=dev)
+    nnz = torch.zeros(1, dtype=torch.int64, device=dev)
+    if n == 0:
+        return rowptr.zero_(), post_doc[:0], post_tf[:0], doclen.zero_(), df.zero_()
+    need = int(load().thr_lexical_build_workspace_bytes(n, n_vocab))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _check(load().thr_lexical_build(pdoc, pterm, ptf, n, n_docs, n_vocab, rowptr.data_ptr(),
+                                    post_doc.data_ptr(), post_tf.data_ptr(), doclen.data_ptr(),
+                                    df.data_ptr(), nnz.data_ptr(), ws.data_ptr(), need, _stream()),
+           "thr_lexical_build")
+    k = int(nnz.item())
+    return rowptr, post_doc[:k].clone(), post_tf[:k].clone(), doclen, df
 
 
 # --------------------------------------------------------------------- a3

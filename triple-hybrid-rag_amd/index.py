@@ -87,7 +87,7 @@ class GpuIndex:
     F16_MAX_REL_ERR = 2e-3       # ~8x the rounding error of rows in float16's normal range
     DENSE_SHARE = 0.01           # lexical terms held by this share of the docs get per-doc rows
 
-    def set_dense(self, docs, shortlist: str = "auto") -> "GpuIndex":
+    def set_dense(self, docs, shortlist: str = "auto", derived: Optional[dict] = None) -> "GpuIndex":
         """How the streaming pass picks its shortlist (the returned scores are ALWAYS the float64
         rescoring of the float32 rows, and the per-query certificate covers the scan's error):
           "f32"        float32 rows on the fp32 matrix cores (32 queries per pass);
@@ -96,6 +96,8 @@ class GpuIndex:
           "f16"        additionally keeps a float16 copy of the rows and streams that;
           "exact"      no shortlist pass: every row scored in float64 (thr_dense_topk_exact) -- any
                        row length that is a multiple of 4;
+          ``derived``: the saved float16 image of a loaded index (export_derived), reused when
+                       its layout is the one this build's scan reads.
           "auto"       an f16 flavour when the dimension has an f16 kernel and every row fits the
                        float16 range -- "f16" while the copy is small next to the device's memory
                        (<= AUTO_COPY_FRACTION of it: a quarter, which covers every shard size the f16 scans
@@ -129,8 +131,14 @@ class GpuIndex:
                 copy_bytes = 2 * self.n_docs * self.dim
                 shortlist = "f16" if copy_bytes <= self.AUTO_COPY_FRACTION * total else "f16-inline"
         if shortlist != "f32":
-            self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
-                                                                 keep_copy=shortlist == "f16")
+            have = derived and derived.get("docs16") is not None and shortlist == "f16" \
+                and derived.get("f16_layout") == N.dense_f16_layout(self.dim)
+            if have:   # (a saved index: the float16 image and its measured error come with it)
+                self.docs16 = self._t(derived["docs16"], torch.float16)
+                self.doc_rel_err = float(derived["doc_rel_err"])
+            else:
+                self.docs16, self.doc_rel_err = N.dense_quantize_f16(self.docs,
+                                                                     keep_copy=shortlist == "f16")
             # float16 holds the rows when no value overflows (|v| < 65504: else the measured error
             # is +inf) and few underflow (rows scaled to ~1e-6 are all subnormals: the error bound
             # would exceed F16_MAX_REL_ERR and no query could be certified)
@@ -143,24 +151,92 @@ class GpuIndex:
         return self
 
     def set_lexical(self, rowptr, post_doc, post_tf, doclen, idf, avgdl: float,
-                    k1: float = 1.2, b: float = 0.75, dense_share: Optional[float] = None) -> "GpuIndex":
+                    k1: float = 1.2, b: float = 0.75, dense_share: Optional[float] = None,
+                    derived: Optional[dict] = None) -> "GpuIndex":
         """``dense_share``: a term held by at least this share of the shard's docs also gets
         per-doc rows of impacts / term frequencies (3 bytes per doc and term; 0 = none;
-        default DENSE_SHARE, or the A/B knob THR_BM25_DENSE_SHARE)."""
+        default DENSE_SHARE, or the A/B knob THR_BM25_DENSE_SHARE).
+        ``derived``: the saved bounds / impacts / dense rows of a loaded index (export_derived):
+        reused when they were computed for the same k1, b, avgdl and dense share."""
         if dense_share is None:
             dense_share = float(os.environ.get("THR_BM25_DENSE_SHARE", self.DENSE_SHARE))
         self.lex = dict(rowptr=self._t(rowptr, torch.int64), post_doc=self._t(post_doc, torch.int32),
                         post_tf=self._t(post_tf, torch.int32), doclen=self._t(doclen, torch.float32),
-                        idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b))
+                        idf=self._t(idf, torch.float64), avgdl=float(avgdl), k1=float(k1), b=float(b),
+                        dense_share=float(dense_share))
         L = self.lex
-        # per-term / per-128-posting score bounds for the WAND-style pruning of thr_bm25_topk
-        L["bounds"] = N.bm25_bounds(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
-                                    L["avgdl"], L["k1"], L["b"])
-        L["dense"] = N.bm25_dense_terms(L["rowptr"], L["post_doc"], L["post_tf"], L["bounds"][2],
-                                        int(L["doclen"].shape[0]), dense_share) if dense_share > 0 else None
+        tag = [L["avgdl"], L["k1"], L["b"], L["dense_share"]]
+        if derived and derived.get("term_ub") is not None and list(derived.get("lexical_tag", [])) == tag:
+            L["bounds"] = (self._t(derived["term_ub"], torch.float64), self._t(derived["block_ub"], torch.float64),
+                           self._t(derived["post_imp"], torch.uint8))
+            L["dense"] = None
+            if derived.get("dense_slot") is not None:
+                L["dense"] = (self._t(derived["dense_slot"], torch.int32), self._t(derived["dense_imp"], torch.uint8),
+                              self._t(derived["dense_tf"], torch.int16), int(derived["dense_stride"]))
+        else:
+            # per-term / per-128-posting score bounds for the WAND-style pruning of thr_bm25_topk
+            L["bounds"] = N.bm25_bounds(L["rowptr"], L["post_doc"], L["post_tf"], L["doclen"], L["idf"],
+                                        L["avgdl"], L["k1"], L["b"])
+            L["dense"] = N.bm25_dense_terms(L["rowptr"], L["post_doc"], L["post_tf"], L["bounds"][2],
+                                            int(L["doclen"].shape[0]), dense_share) if dense_share > 0 else None
         if self.n_docs == 0:
             self.n_docs = int(self.lex["doclen"].shape[0])
         return self
+
+    def set_lexical_rows(self, doc, term, tf, n_vocab: int, n_docs: Optional[int] = None,
+                         n_docs_global: Optional[int] = None, group=None, k1: float = 1.2,
+                         b: float = 0.75, dense_share: Optional[float] = None) -> "GpuIndex":
+        """The lexical side from tokenised ROWS, built on the device (thr_lexical_build): ``doc`` /
+        ``term`` / ``tf`` int32 [n_pairs] -- one entry per distinct (doc, term) of a chunk, or one
+        per token occurrence with ``tf`` None; doc ids LOCAL to this shard.  A document shard
+        passes the corpus' ``n_docs_global`` and its process ``group``: the per-term document
+        frequencies and the length total are all-reduced over the shards, so idf and avgdl are the
+        whole corpus'  -- idf itself is float64 numpy on the host, the oracle's formula
+        to the bit.  The reference leaves this step to PostgreSQL's generated tsvector column +
+        GIN index (rag2_schema.sql:146-148, 171-172; rows from rag2/ingest.py:361-470)."""
+        import torch.distributed as dist
+        n = int(n_docs if n_docs is not None else self.n_docs)
+        if n <= 0:
+            raise N.NativeError("set_lexical_rows: the shard's doc count is unknown (n_docs)")
+        rowptr, post_doc, post_tf, doclen, df = N.lexical_build(
+            self._t(doc, torch.int32), self._t(term, torch.int32),
+            None if tf is None else self._t(tf, torch.int32), n, int(n_vocab))
+        sum_dl = doclen.sum(dtype=torch.float64).reshape(1)
+        df_glob = df.clone()
+        if group is not None or (dist.is_initialized() and n_docs_global is not None and n_docs_global != n):
+            if dist.get_backend(group) == "gloo":   # (CPU rendezvous: rehearsals and tests)
+                df_c, sd_c = df_glob.cpu(), sum_dl.cpu()
+                dist.all_reduce(df_c, group=group)
+                dist.all_reduce(sd_c, group=group)
+                df_glob, sum_dl = df_c.to(self.device), sd_c.to(self.device)
+            else:
+                dist.all_reduce(df_glob, group=group)
+                dist.all_reduce(sum_dl, group=group)
+        n_glob = int(n_docs_global if n_docs_global is not None else n)
+        dfh = df_glob.cpu().numpy().astype(np.float64)
+        idf = np.log(1.0 + (float(n_glob) - dfh + 0.5) / (dfh + 0.5))
+        avgdl = float(sum_dl.item()) / max(n_glob, 1)
+        self.df_local, self.df_global = df, df_glob
+        return self.set_lexical(rowptr, post_doc, post_tf, doclen, idf, avgdl if avgdl > 0 else 1.0, k1, b,
+                                dense_share)
+
+    def export_derived(self) -> dict:
+        """What index set-up computed on the device and a saved index can carry along, as host
+        arrays: the float16 image of the rows (+ its layout tag and measured error), the BM25
+        bounds / per-posting impacts and the dense-term rows (+ the parameters they hold for)."""
+        out: dict = {}
+        if self.docs16 is not None and self.shortlist == "f16":
+            out.update(docs16=self.docs16.cpu().numpy(), doc_rel_err=float(self.doc_rel_err),
+                       f16_layout=N.dense_f16_layout(self.dim))
+        if self.lex is not None:
+            L = self.lex
+            out.update(term_ub=L["bounds"][0].cpu().numpy(), block_ub=L["bounds"][1].cpu().numpy(),
+                       post_imp=L["bounds"][2].cpu().numpy(),
+                       lexical_tag=[L["avgdl"], L["k1"], L["b"], L["dense_share"]])
+            if L["dense"] is not None:
+                out.update(dense_slot=L["dense"][0].cpu().numpy(), dense_imp=L["dense"][1].cpu().numpy(),
+                           dense_tf=L["dense"][2].cpu().numpy(), dense_stride=int(L["dense"][3]))
+        return out
 
     def set_collections(self, doc_coll) -> "GpuIndex":
         """Per-document collection id (int32 [n], any non-negative labelling): the

@@ -8,7 +8,16 @@ confidence])`` (database/migrations/20260114_rag2_schema.sql:104-283;
 src/voice_agent/rag2/ingest.py:361-470) -- into the GPU-resident arrays / CSRs and the host
 row store, and saves / loads them as a directory of ``.npy`` files + one JSON.
 
-Host-side numpy: this is offline index construction, not the query path.
+Two routes to the lexical index.  ``build_lexical`` is host numpy (what runs without a GPU:
+small corpora, the CPU tests).  ``from_rows(..., device=True)`` / ``lexical_rows`` +
+``GpuIndex.set_lexical_rows`` tokenise at C speed on the host (one regex pass per chunk, one
+hash factorisation of all tokens) and build the CSR ON THE DEVICE (thr_lexical_build: radix sort
+of the (term, doc) pairs, segmented reduce, row pointers by binary search) -- a 1M-chunk shard's
+32M postings in well under a second; document shards all-reduce their df / length sums for the
+global idf / avgdl.  ``save`` writes, next to the source arrays, what index set-up computed on
+the device (``GpuIndex.export_derived``: the float16 image of the rows, the BM25 bounds /
+impacts / dense-term rows) and ``load(...).to_gpu()`` reuses them; the row payloads live in
+blob + offset files (``StringColumn``), not in ``meta.json``.
 """
 from __future__ import annotations
 
@@ -41,19 +50,70 @@ class HostIndex:
     men_conf: Optional[np.ndarray] = None
     tokens: Optional[np.ndarray] = None   # f16 [n, T, 128]
     store: Optional[CorpusStore] = None
+    derived: Optional[Dict[str, Any]] = None   # GpuIndex.export_derived(): saved with the index, reused by to_gpu()
 
     def to_gpu(self, doc_base: int = 0):
         from .index import GpuIndex
-        idx = GpuIndex(doc_base=doc_base).set_dense(self.docs)
+        idx = GpuIndex(doc_base=doc_base).set_dense(self.docs, derived=self.derived)
         if self.rowptr is not None:
             idx.set_lexical(self.rowptr, self.post_doc, self.post_tf, self.doclen, self.idf,
-                            self.avgdl, K1, B)
+                            self.avgdl, K1, B, derived=self.derived)
         if self.ent_rowptr is not None:
             idx.set_graph(self.ent_rowptr, self.ent_col, self.men_rowptr, self.men_chunk,
                           self.men_conf)
         if self.tokens is not None:
             idx.set_tokens(self.tokens)
         return idx
+
+
+class StringColumn(Sequence):
+    """A column of strings as ONE utf-8 blob + int64 offsets (memory-mapped when loaded): what a
+    10M-row store keeps instead of ten million Python objects in a JSON file.  Decodes on access."""
+
+    def __init__(self, blob, offsets):
+        self.blob, self.offsets = blob, offsets
+
+    @classmethod
+    def from_strings(cls, values: Sequence[Optional[str]]) -> "StringColumn":
+        enc = [b"\x00" if v is None else str(v).encode("utf-8") for v in values]   # (NUL alone = None)
+        off = np.zeros(len(enc) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=len(enc)), out=off[1:])
+        return cls(np.frombuffer(b"".join(enc), dtype=np.uint8), off)
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        raw = bytes(self.blob[int(self.offsets[i]):int(self.offsets[i + 1])])
+        return None if raw == b"\x00" else raw.decode("utf-8")
+
+    def __eq__(self, other):
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+    __hash__ = None
+
+
+def lexical_rows(texts: Sequence[str], tokenizer: Callable[[str], List[str]] = tokenize,
+                 vocab: Optional[Dict[str, int]] = None):
+    """Texts -> (vocab, doc int32 [n_tokens], term int32 [n_tokens]): one entry per token
+    occurrence, term -1 for a token outside a given ``vocab`` (it still counts toward its chunk's
+    length).  One tokenizer call per chunk, then array work: a new vocabulary numbers the tokens in
+    order of first appearance (pandas' hash factorisation), exactly as ``build_lexical`` does."""
+    import itertools
+    per_doc = [tokenizer(t) for t in texts]
+    lens = np.fromiter(map(len, per_doc), dtype=np.int64, count=len(per_doc))
+    flat = list(itertools.chain.from_iterable(per_doc))
+    doc = np.repeat(np.arange(len(per_doc), dtype=np.int32), lens)
+    if vocab is None:
+        import pandas as pd
+        codes, uniques = pd.factorize(np.asarray(flat, dtype=object)) if flat else (np.zeros(0, np.int64), [])
+        return {tok: i for i, tok in enumerate(uniques)}, doc, codes.astype(np.int32)
+    term = np.fromiter((vocab.get(t, -1) for t in flat), dtype=np.int32, count=len(flat))
+    return vocab, doc, term
 
 
 def build_lexical(texts: Sequence[str], tokenizer: Callable[[str], List[str]] = tokenize,
@@ -134,9 +194,12 @@ def build_graph(entity_ids: Sequence[Any], relations: Iterable[Dict[str, Any]],
 def from_rows(child_rows: Sequence[Dict[str, Any]], parent_rows: Sequence[Dict[str, Any]] = (),
               entity_rows: Sequence[Dict[str, Any]] = (), relation_rows: Sequence[Dict[str, Any]] = (),
               mention_rows: Sequence[Dict[str, Any]] = (), embedding_key: str = "embedding_1024",
-              tokenizer: Callable[[str], List[str]] = tokenize, doc_base: int = 0) -> HostIndex:
+              tokenizer: Callable[[str], List[str]] = tokenize, doc_base: int = 0,
+              device: bool = False) -> HostIndex:
     """Reference table rows -> HostIndex (+ CorpusStore).  Rows without an embedding keep a
-    zero vector, i.e. are excluded from the dense channel (``embedding_1024 IS NOT NULL``)."""
+    zero vector, i.e. are excluded from the dense channel (``embedding_1024 IS NOT NULL``).
+    device=True builds the inverted index on the GPU (``lexical_rows`` + thr_lexical_build) and
+    brings the arrays back for ``save``; the result equals the host route's."""
     n = len(child_rows)
     dim = next((len(r[embedding_key]) for r in child_rows if r.get(embedding_key) is not None), 0)
     docs = np.zeros((n, dim), dtype=np.float32)
@@ -144,7 +207,18 @@ def from_rows(child_rows: Sequence[Dict[str, Any]], parent_rows: Sequence[Dict[s
         if r.get(embedding_key) is not None:
             docs[i] = np.asarray(r[embedding_key], dtype=np.float32)
     texts = [r.get("text", "") for r in child_rows]
-    vocab, rowptr, pd, ptf, dl, idf, avgdl = build_lexical(texts, tokenizer)
+    if device:
+        from . import _native as N
+        import torch
+        vocab, d_tok, t_tok = lexical_rows(texts, tokenizer)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rowptr, pd, ptf, dl, df = (a.cpu().numpy() for a in N.lexical_build(
+            torch.from_numpy(d_tok).to(dev), torch.from_numpy(t_tok).to(dev), None, n, max(len(vocab), 1)))
+        dfh = df.astype(np.float64)
+        idf = np.log(1.0 + (float(n) - dfh + 0.5) / (dfh + 0.5))
+        avgdl = float(dl.astype(np.float64).sum()) / max(n, 1) or 1.0
+    else:
+        vocab, rowptr, pd, ptf, dl, idf, avgdl = build_lexical(texts, tokenizer)
     store = CorpusStore(
         child_ids=[r["id"] for r in child_rows], parent_ids=[r.get("parent_id") for r in child_rows],
         document_ids=[r.get("document_id") for r in child_rows], texts=texts,
@@ -166,20 +240,46 @@ def from_rows(child_rows: Sequence[Dict[str, Any]], parent_rows: Sequence[Dict[s
 
 _ARRAYS = ("docs", "rowptr", "post_doc", "post_tf", "doclen", "idf", "ent_rowptr", "ent_col",
            "men_rowptr", "men_chunk", "men_conf", "tokens")
+_DERIVED_ARRAYS = ("docs16", "term_ub", "block_ub", "post_imp", "dense_slot", "dense_imp", "dense_tf")
+_DERIVED_SCALARS = ("doc_rel_err", "f16_layout", "lexical_tag", "dense_stride")
+_STRING_COLUMNS = ("child_ids", "parent_ids", "document_ids", "texts", "modalities", "collections",
+                   "entity_names")
 
 
-def save(hi: HostIndex, path: str) -> None:
+def save(hi: HostIndex, path: str, gpu_index=None) -> None:
+    """``gpu_index``: the GpuIndex built from ``hi`` -- what its set-up computed on the device
+    (export_derived) is saved too, so that a later ``load(path).to_gpu()`` does not recompute it."""
     os.makedirs(path, exist_ok=True)
     for name in _ARRAYS:
         arr = getattr(hi, name)
         if arr is not None:
             np.save(os.path.join(path, name + ".npy"), arr, allow_pickle=False)
-    meta: Dict[str, Any] = {"avgdl": hi.avgdl, "format": 1}
+    meta: Dict[str, Any] = {"avgdl": hi.avgdl, "format": 2}
+    derived = gpu_index.export_derived() if gpu_index is not None else hi.derived
+    if derived:
+        for name in _DERIVED_ARRAYS:
+            if derived.get(name) is not None:
+                np.save(os.path.join(path, "derived_" + name + ".npy"), np.asarray(derived[name]), allow_pickle=False)
+        meta["derived"] = {k: derived[k] for k in _DERIVED_SCALARS if derived.get(k) is not None}
     if hi.store is not None:
         s = hi.store
-        meta["store"] = {k: getattr(s, k) for k in ("child_ids", "parent_ids", "document_ids", "texts",
-                                                     "pages", "modalities", "parents", "collections",
-                                                     "vocab", "entity_names", "doc_base")}
+        columns = []
+        for name in _STRING_COLUMNS:   # the big columns: blob + offsets, not JSON
+            values = getattr(s, name)
+            if values is None:
+                continue
+            col = values if isinstance(values, StringColumn) else StringColumn.from_strings(values)
+            np.save(os.path.join(path, f"store_{name}_blob.npy"), np.asarray(col.blob), allow_pickle=False)
+            np.save(os.path.join(path, f"store_{name}_off.npy"), np.asarray(col.offsets), allow_pickle=False)
+            columns.append(name)
+        np.save(os.path.join(path, "store_pages.npy"), np.asarray(s.pages, dtype=np.int32), allow_pickle=False)
+        voc = list(s.vocab.items())
+        vcol = StringColumn.from_strings([k for k, _ in voc])
+        np.save(os.path.join(path, "store_vocab_blob.npy"), np.asarray(vcol.blob), allow_pickle=False)
+        np.save(os.path.join(path, "store_vocab_off.npy"), np.asarray(vcol.offsets), allow_pickle=False)
+        np.save(os.path.join(path, "store_vocab_ids.npy"), np.asarray([v for _, v in voc], dtype=np.int64),
+                allow_pickle=False)
+        meta["store"] = {"columns": columns, "parents": s.parents, "doc_base": s.doc_base}
     with open(os.path.join(path, "meta.json"), "w") as f:
         json.dump(meta, f)
 
@@ -187,10 +287,28 @@ def save(hi: HostIndex, path: str) -> None:
 def load(path: str, mmap: bool = True) -> HostIndex:
     with open(os.path.join(path, "meta.json")) as f:
         meta = json.load(f)
-    arrays = {}
-    for name in _ARRAYS:
+    mode = "r" if mmap else None
+
+    def arr(name):
         fp = os.path.join(path, name + ".npy")
-        arrays[name] = np.load(fp, mmap_mode="r" if mmap else None, allow_pickle=False) \
-            if os.path.exists(fp) else None
-    store = CorpusStore(**meta["store"]) if "store" in meta else None
-    return HostIndex(avgdl=meta["avgdl"], store=store, **arrays)
+        return np.load(fp, mmap_mode=mode, allow_pickle=False) if os.path.exists(fp) else None
+    arrays = {name: arr(name) for name in _ARRAYS}
+    derived = None
+    if "derived" in meta:
+        derived = dict(meta["derived"])
+        derived.update({name: arr("derived_" + name) for name in _DERIVED_ARRAYS})
+    store = None
+    if "store" in meta:
+        ms = meta["store"]
+        if "columns" not in ms:    # format 1: everything in the JSON
+            store = CorpusStore(**ms)
+        else:
+            cols = {name: StringColumn(arr(f"store_{name}_blob"), arr(f"store_{name}_off")) for name in ms["columns"]}
+            vcol = StringColumn(arr("store_vocab_blob"), arr("store_vocab_off"))
+            vocab = dict(zip(vcol, (int(v) for v in arr("store_vocab_ids"))))
+            store = CorpusStore(child_ids=cols["child_ids"], parent_ids=cols["parent_ids"],
+                                document_ids=cols["document_ids"], texts=cols["texts"],
+                                pages=arr("store_pages").tolist(), modalities=cols["modalities"], parents=ms["parents"],
+                                collections=cols.get("collections"), vocab=vocab,
+                                entity_names=cols.get("entity_names", []), doc_base=ms["doc_base"])
+    return HostIndex(avgdl=meta["avgdl"], store=store, derived=derived, **arrays)
