@@ -2,7 +2,7 @@
 """Where the float16-copy scan spends its time: per-phase s_memtime sums of every wave
 (thr_dense_scan_stamps_f16), at the bench shape.  Only the 4-wave-block kernel dense_scan_f16q has a
 stamped build: run with THR_DENSE_F16=q at dim <= 768 (the default staggered kernel answers
-"unsupported shape").  THR_DENSE_F16=q python3 scripts/scan_stamps.py [queries] [docs]"""
+"unsupported shape").  THR_DENSE_F16=q python3 scripts/scan_stamps.py [queries] [docs] [dim]"""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ def main():
     from triple_hybrid_rag_amd import synth
     nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-    d = 768
+    d = int(sys.argv[3]) if len(sys.argv) > 3 else 768
     x = torch.from_numpy(synth.dense_rows(0, n, d)).cuda()
     q = torch.from_numpy(synth.dense_queries(nq, d, n)).cuda()
     idx = T.GpuIndex().set_dense(x, shortlist="f16")
