@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_dense -o dense -
 python3 bench.py --docs 125000 --config dense --no-extras --no-cpu-baseline > $D/bench_shard125k.json.log 2>&1
 python3 bench.py --docs 500000 --config dense --no-extras --no-cpu-baseline > $D/bench_shard500k.json.log 2>&1
 python3 bench.py --dim 1024 --config dense --no-extras --no-cpu-baseline > $D/bench_dim1024.json.log 2>&1
+python3 bench.py --docs 1250000 --config triple --no-extras --no-cpu-baseline > $D/bench_shard1250k_triple.json.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_triple -o triple -- python3 bench.py --config triple --no-extras --no-cpu-baseline --steps 6 > $D/bench_triple_profiled.log 2>&1
 python3 bench.py --lexical-mix no-stopwords --no-cpu-baseline > $D/bench_no_stopwords.json.log 2>&1
 bash scripts/pmc_passes.sh $D/pmc_scan 2048 > $D/pmc_scan.log 2>&1
 python3 scripts/pmc_counters.py $D/pmc_scan dense_scan_f16qs $D/scan_f16qs_counters.json "768, 1" > $D/pmc_fold.log 2>&1
