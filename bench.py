@@ -45,7 +45,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 CONFIGS = ("dense", "dense_bm25", "triple", "triple_rerank")
 BASELINE_CONFIG = {"dense": "configs[1]", "dense_bm25": "configs[2]", "triple": "configs[3]",
                    "triple_rerank": "configs[4]"}
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r3_scan_f16qs_counters.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r4_scan_f16qs_counters.json")
 
 
 def parse():
