@@ -51,6 +51,19 @@ namespace thr {
 
 typedef unsigned short bm_u16x2 __attribute__((ext_vector_type(2)));
 
+// What bm25_walk_wave_kernel needs of an item and of its terms, gathered by bm25_edges_kernel so that
+// a wave's set-up is two dependent loads, not five (item -> query words -> term ids -> list heads).
+struct WwItem {
+    int32_t q, sl, SA, S, nt, pm, qc, pad;
+};
+struct WwTerm {
+    int64_t lo;     // first posting of the term's slice (absolute)
+    double idf, ub;
+    int64_t row;    // probed term: offset of its per-doc row; else -1
+    int32_t len;    // postings of the slice (0 for a probed term)
+    int32_t pad;
+};
+
 struct TermRange {
     int64_t lo;   // first posting of the term
     int len;      // postings of the term
@@ -192,7 +205,7 @@ __device__ __forceinline__ int64_t bm_window_edge(int64_t n_docs, int s, int S) 
 
 __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int64_t* __restrict__ rowptr, int64_t n_vocab, const int32_t* __restrict__ query_terms,
-    int nq, int mt, int cap, int conjunctive, int n_slots, int target_max, int walk_div,
+    int nq, int mt, int cap, int cap_wave, int conjunctive, int n_slots, int target_max, int target_a0, int wave_mode, int walk_div,
     const int32_t* __restrict__ dense_slot, const double* __restrict__ term_ub, int64_t n_docs,
     int32_t* __restrict__ ctl, int64_t* __restrict__ q_tot, double* __restrict__ q_dub,
     int32_t* __restrict__ q_nt, int32_t* __restrict__ q_S, int32_t* __restrict__ q_SA,
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     // lengths / bounds / row slots -- are the kernel's time: one query per thread, the workgroups of
     // the grid on different CUs; round 3 ran this on ONE workgroup, two queries per thread: 62 us)
     __shared__ int red[PLAN_THREADS];
-    int n_dp = 0;
+    int n_dp = 0, n_blk = 0;
     for (int q = blockIdx.x * PLAN_THREADS + threadIdx.x; q < nq; q += gridDim.x * PLAN_THREADS) {
         int nt = 0, lng = 0;
         long long tot = 0, best = -1;
@@ -297,16 +310,25 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
                 tot += len;
             }
         }
-        q_SA[q] = pmask ? 0 : -1;                  // (slice counts: below, once the target is known)
-        q_pmask[q] = (int32_t)pmask;
+        // Wave mode (bm25_walk_wave_kernel): an OR query of <= 8 terms WITHOUT probed terms is walked by
+        // waves too -- it is a stage A with nothing probed and no stage B: bit 30 marks it, all its
+        // slices are stage-A slices (q_SA == q_S), cut with the waves' slice size.
+        const bool wave_q = wave_mode && !conjunctive && nt >= 1 && nt <= 8 && !pmask;
+        q_SA[q] = (pmask || wave_q) ? 0 : -1;      // (slice counts: below, once the target is known)
+        if (!(pmask || wave_q)) ++n_blk;           // (left to the workgroup walk)
+        q_pmask[q] = (int32_t)pmask | (wave_q ? (1 << 30) : 0);
         q_dub[q] = dub;
         q_tot[q] = pmask ? -(walked + 1) : tot;    // dense terms: -(postings of the walked terms + 1)
         q_nt[q] = nt;
         q_long[q] = lng;
     }
     {   // queries with probed terms: one atomic per wave
-        for (int o = WAVE / 2; o > 0; o >>= 1) n_dp += __shfl_down(n_dp, o, WAVE);
+        for (int o = WAVE / 2; o > 0; o >>= 1) {
+            n_dp += __shfl_down(n_dp, o, WAVE);
+            n_blk += __shfl_down(n_blk, o, WAVE);
+        }
         if ((threadIdx.x & (WAVE - 1)) == 0 && n_dp) atomicAdd(&ctl[3], n_dp);
+        if ((threadIdx.x & (WAVE - 1)) == 0 && n_blk) atomicAdd(&ctl[8], n_blk);   // queries the workgroup walk takes
     }
     // Part 2, the workgroup that finishes last: slice size, item list.  (Its reads of the other
     // workgroups' per-query words go to L2: agent-scope atomic loads.)
@@ -319,6 +341,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     __threadfence();
     auto tot_of = [&](int q) -> long long {
         return (long long)__hip_atomic_load(&q_tot[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto wave_q_of = [&](int q) -> bool {   // an ordinary query the waves walk (bit 30 of its probe mask)
+        return (__hip_atomic_load(&q_pmask[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 30) & 1;
     };
     const int per = (nq + PLAN_THREADS - 1) / PLAN_THREADS;
     const int q0 = threadIdx.x * per < nq ? threadIdx.x * per : nq;
@@ -340,22 +365,46 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     }
     long long target = red64[0] / (n_slots > 0 ? n_slots : 1);
     target = target < BM_TARGET_MIN ? BM_TARGET_MIN : target > target_max ? target_max : target;
+    // stage-A slices have their own size when a wave, not a workgroup, takes one (bm25_walk_wave_kernel)
+    long long target_a = target_a0 > 0 ? target_a0 : target;
+    // ``cap`` items for the sweeps and the workgroup walk's items (the slice size that budget gives them
+    // was tuned with it), ``cap_wave`` more for the waves' ~1 K-posting slices
+    __shared__ int red_w[PLAN_THREADS];
     int total = 0, mine = 0;
     for (;;) {
         mine = 0;
+        int mine_w = 0;
         for (int q = q0; q < q1; ++q) {
             const long long v = tot_of(q);
-            mine += v >= 0 ? bm_slices(v, target) : bm_slices_a(-v - 1, target) + bm_slices(n_docs, target);
+            if (v >= 0) {
+                if (wave_q_of(q)) mine_w += bm_slices(v, target_a);
+                else mine += bm_slices(v, target);
+            } else {
+                const int sa = bm_slices_a(-v - 1, target_a);
+                if (wave_mode) mine_w += sa; else mine += sa;
+                mine += bm_slices(n_docs, target);
+            }
         }
         red[threadIdx.x] = mine;
+        red_w[threadIdx.x] = mine_w;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            if ((int)threadIdx.x < o) {
+                red[threadIdx.x] += red[threadIdx.x + o];
+                red_w[threadIdx.x] += red_w[threadIdx.x + o];
+            }
             __syncthreads();
         }
-        total = red[0];
+        total = red[0] + red_w[0];
+        const bool fits = red[0] <= cap && red_w[0] <= cap_wave;
+        const bool grow_w = red_w[0] > cap_wave;
         __syncthreads();
-        if (total <= cap) break;   // (every query is one or two items once target >= its total: terminates)
+        mine += mine_w;
+        if (fits) break;   // (every query is one or two items once the targets reach its totals: terminates)
+        if (grow_w) {
+            target_a *= 2;
+            continue;
+        }
         target *= 2;
     }
     // exclusive prefix of the per-thread item counts
@@ -377,9 +426,11 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         int S = 0;
         const long long v = tot_of(q);
         if (v >= 0) {
-            S = bm_slices(v, target);
+            const bool wq = wave_q_of(q);
+            S = bm_slices(v, wq ? target_a : target);
+            if (wq) q_SA[q] = S;
         } else {
-            const int SA = bm_slices_a(-v - 1, target);
+            const int SA = bm_slices_a(-v - 1, target_a);
             q_SA[q] = SA;
             S = SA + bm_slices(n_docs, target);
         }
@@ -389,7 +440,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
         for (int s = 1; s < S; ++s) items[nq + rest + s - 1] = make_int2(q, s);
         rest += S - 1;
     }
-    if (threadIdx.x == 0) ctl[0] = total;
+    if (threadIdx.x == 0) {
+        ctl[0] = total;
+        ctl[7] = (int)(target_a > 0x7fffffff ? 0x7fffffff : target_a);   // (what a stage-A slice was aimed at)
+    }
 }
 
 __global__ __launch_bounds__(256) void bm25_edges_kernel(
@@ -397,12 +451,21 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
     const int32_t* __restrict__ ctl, const int32_t* __restrict__ q_nt,
     const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA, const int32_t* __restrict__ q_long,
     const int32_t* __restrict__ q_terms, const int2* __restrict__ items, int mt,
-    const int32_t* __restrict__ q_pmask, int64_t n_docs, int32_t* __restrict__ ipos) {
+    const int32_t* __restrict__ q_pmask, int64_t n_docs, int32_t* __restrict__ ipos,
+    const double* __restrict__ idf, const double* __restrict__ term_ub, const int32_t* __restrict__ dense_slot,
+    int64_t dense_stride, const int32_t* __restrict__ query_coll, WwItem* __restrict__ wrec,
+    WwTerm* __restrict__ wterm) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int item = (int)(g / mt), slot = (int)(g % mt);
     if (item >= ctl[0]) return;
     const int2 it = items[item];
     const int q = it.x;
+    if (wrec && slot == 0) {
+        WwItem r;
+        r.q = q; r.sl = it.y; r.SA = q_SA[q]; r.S = q_S[q]; r.nt = q_nt[q]; r.pm = q_pmask[q] & 0xFF;
+        r.qc = query_coll ? query_coll[q] : -1; r.pad = 0;
+        wrec[item] = r;
+    }
     if (slot >= q_nt[q]) return;
     const int term = q_terms[(int64_t)q * mt + slot];
     const int64_t lo = rowptr[term];
@@ -439,6 +502,17 @@ __global__ __launch_bounds__(256) void bm25_edges_kernel(
     }
     ipos[((int64_t)item * mt + slot) * 2] = start;
     ipos[((int64_t)item * mt + slot) * 2 + 1] = end;
+    if (wterm && slot < 8 && SA >= 0 && !sweep) {
+        const bool probed = (q_pmask[q] >> slot) & 1;
+        WwTerm t;
+        t.lo = lo + start;
+        t.idf = idf[term];
+        t.ub = term_ub[term];
+        t.row = probed ? (int64_t)dense_slot[term] * dense_stride : -1;
+        t.len = probed ? 0 : end - start;
+        t.pad = 0;
+        wterm[(int64_t)item * 8 + slot] = t;
+    }
 }
 
 // An item's postings are consumed in DOC-RANGE passes.  A pass stages, from every term's list,
@@ -555,6 +629,9 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
         // stage-A slices together -- two half-empty persistent grids, each with its own tail, cost
         // more than the row probes' registers cost the ordinary items (256 / 2048 survey queries:
         // 0.85 -> 0.60 / 1.83 -> 1.55 ms; a batch without dense terms: 0.49 -> 0.55 ms, hence the switch).
+        // (fuse_div < 0: wave mode -- the waves took every OR query of <= 8 terms; this launch has the
+        // rest, and nothing to do at all when the plan counted none)
+        if (fuse_div < 0 && ctl[8] == 0) return;
         const int nd = ctl[3];
         const bool fuse = fuse_div > 0 && nd > 0 && (long long)nd * fuse_div >= n_queries;
         if (DPM == 2 ? !fuse : DPM == 1 ? (fuse || nd == 0) : fuse) return;
@@ -1312,6 +1389,463 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// bm25_walk_wave_kernel: stage A (the walked terms of a query with probed terms) with a WAVE, not a
+// workgroup, per work item.
+//
+// Why (round 4): the block walk above gives an item to 512 threads that run a chain of
+// barrier-separated phases, each a dependent memory round trip; a stage-A item is ~3 K postings,
+// its fixed latency ~60 us, two workgroups fit a CU -- the kernel's waves wait 82 % of their life
+// and 40 % of its cycles are per-item latency.  The work itself is embarrassingly parallel over
+// items, so the way to hide a latency chain is MORE CHAINS PER CU, not more threads per chain:
+// here an item is a doc-range slice of ~1 K walked postings (the plan cuts stage A with its own,
+// smaller target), ONE wave walks it without a single workgroup barrier, and sixteen waves --
+// sixteen independent chains -- share a CU (10 KiB of LDS and <= 128 VGPRs per wave).
+//
+// Per pass (an item is one pass unless a doc-range slice came out longer than the stage):
+//   stage     the next ids of every walked list into the wave's LDS (equal quotas; d_hi = the
+//             smallest "last staged doc + 1" among lists with more behind: every posting below
+//             d_hi of every list is on chip);
+//   bits      a Bloom bit per (list, doc) when more than one list has postings;
+//   classify  a posting whose doc shows in no other list's bits is its doc's only one: held against
+//             the threshold with its own quantised impact + the probed terms' largest, listed when it
+//             may enter; the others go to a work list;
+//   score     listed singles 64 at a time: doc length, own tf, the probed terms' frequencies from
+//             their rows, float64 in query-term order, wave-level top-k (128 slots, bitonic cut);
+//             as soon as k docs are in, the cut gives a threshold and the classification goes on
+//             with it; work-list postings find their owner and the other lists' positions by
+//             binary search in LDS.
+// Same arithmetic, same bounds (bm25_topk_kernel's accumulator units), same threshold sharing
+// (theta_glob) and slice lists as the block walk: results are the same bits.  k <= 64.
+// ---------------------------------------------------------------------------------------------
+constexpr int WW_WAVES = 4;        // waves per workgroup (independent: they never synchronise)
+constexpr int WW_STAGE = 1024;     // doc ids a wave stages per pass
+constexpr int WW_CAP = 128;        // top-k slots of a wave (k <= 64: a batch of 64 always fits after a cut)
+constexpr int WW_BLOOM = 256;      // words of Bloom bits per wave, shared out among the lists with postings
+constexpr int WW_TARGET = 1024;    // postings per stage-A slice the plan aims at
+constexpr int BM_WAVE_ITEMS = 16384;   // item slots for the waves' slices, on top of the list's capacity
+
+struct WwLds {
+    int32_t st_doc[WW_STAGE];
+    uint8_t st_imp[WW_STAGE];      // the staged postings' quantised impacts (the bound test never leaves LDS)
+    uint16_t list[WW_STAGE];       // singles to score from the front, postings to search from the back
+    double b_s[WW_CAP];
+    int32_t b_id[WW_CAP];
+    uint32_t bloom[WW_BLOOM];
+    int64_t t_lo[8];               // first posting of the term's slice
+    int64_t t_row[8];              // probed term: offset of its per-doc row; else -1
+    double t_idf[8];
+    int t_len[8], t_cur[8], t_sub[8], t_off[8], t_w[8], t_stg[8], t_bs[8];
+};
+
+__device__ __forceinline__ void ww_sync() {
+    // lanes of ONE wave exchange data through LDS: the hardware keeps a wave's LDS accesses in
+    // order; this keeps the compiler from moving or caching them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// descending (score, then ascending id) bitonic sort of the WW_CAP slots by one wave: two slots per lane
+__device__ __forceinline__ void ww_sort(double* s, int32_t* id, int lane) {
+    for (int k2 = 2; k2 <= WW_CAP; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const int i = ((lane & ~(j - 1)) << 1) | (lane & (j - 1)), p = i | j;
+            const bool up = (i & k2) == 0;
+            const double sa = s[i], sb = s[p];
+            const int32_t ia = id[i], ib = id[p];
+            const bool swap = up ? better(sb, (int64_t)ib, sa, (int64_t)ia) : better(sa, (int64_t)ia, sb, (int64_t)ib);
+            if (swap) {
+                s[i] = sb; s[p] = sa;
+                id[i] = ib; id[p] = ia;
+            }
+            ww_sync();
+        }
+}
+
+__global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
+    const int64_t* __restrict__ rowptr, const int32_t* __restrict__ post_doc,
+    const int32_t* __restrict__ post_tf, const float* __restrict__ doclen,
+    const double* __restrict__ idf, const double* __restrict__ term_ub,
+    const uint8_t* __restrict__ post_imp, const int32_t* __restrict__ dense_slot,
+    const uint16_t* __restrict__ dense_tf, int64_t dense_stride, double avgdl, double k1, double b,
+    int64_t id_base, int max_terms, int k, const int32_t* __restrict__ doc_coll,
+    const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
+    const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
+    const int32_t* __restrict__ q_pmask, const int32_t* __restrict__ q_terms,
+    const int2* __restrict__ items, const int32_t* __restrict__ ipos, const WwItem* __restrict__ wrec,
+    const WwTerm* __restrict__ wterm,
+    unsigned long long* __restrict__ theta_glob, double* __restrict__ slice_s,
+    int64_t* __restrict__ slice_id, int32_t* __restrict__ slice_cnt, double* __restrict__ out_s,
+    int64_t* __restrict__ out_id, int32_t* __restrict__ out_cnt
+#ifdef BM_STAMPS
+    , unsigned long long* __restrict__ wstamps
+#endif
+    ) {
+#ifdef BM_STAMPS
+    unsigned long long ws_acc[16] = {0};
+    unsigned long long ws_last = __builtin_readcyclecounter();
+#define WW_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); ws_acc[i] += now_ - ws_last; ws_last = now_; } while (0)
+#define WW_C(i, v) do { ws_acc[i] += (unsigned long long)(v); } while (0)
+#else
+#define WW_T(i)
+#define WW_C(i, v)
+#endif
+    __shared__ WwLds lds_all[WW_WAVES];
+    const int lane = threadIdx.x & 63;
+    WwLds& L = lds_all[threadIdx.x >> 6];
+    const int n_items = ctl[0];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        // a wave's first item is its own number (thousands of waves bumping one counter at launch spend
+    // tens of microseconds in the L2's atomic unit: an EMPTY launch took 72 us that way); the counter
+    // hands out the items behind those
+    const int n_waves = (int)gridDim.x * WW_WAVES;
+    int item = (int)blockIdx.x * WW_WAVES + (int)(threadIdx.x >> 6);
+    bool first = true;
+    for (;; first = false) {
+        if (!first) {
+            if (lane == 0) item = atomicAdd(&ctl[4], 1) + n_waves;
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
+        if (item >= n_items) break;
+        const WwItem rec = wrec[item];
+        const int q = rec.q, sl = rec.sl, SA = rec.SA;
+        if (!(SA >= 0 && sl < SA)) {                    // not a stage-A slice: another kernel's item
+            WW_T(7);
+            continue;
+        }
+        const int S = rec.S, nt = rec.nt, pm = rec.pm, qc = rec.qc;
+        // ---- the terms (lane t < 8), then everything uniform the passes need ----
+        double scale_l = 0.0;
+        int dm_l = 0;
+        {
+            const bool on = lane < nt && lane < 8;
+            WwTerm tr_;
+            tr_.lo = 0; tr_.idf = 0.0; tr_.ub = 0.0; tr_.row = -1; tr_.len = 0; tr_.pad = 0;
+            if (on) tr_ = wterm[(int64_t)item * 8 + lane];
+            const bool probed = on && ((pm >> lane) & 1);
+            const int64_t lo = tr_.lo;
+            const int start = 0, end = tr_.len;
+            const double idf_l = tr_.idf;
+            const double ubt = tr_.ub;
+            const int64_t row_l = tr_.row;
+            // integer weights of the quantised impacts, as bm25_topk_kernel computes them
+            const double c = (k1 + 1.0) / 255.0;
+            double sum = idf_l * c;
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);   // (lanes 0..7 hold the terms; 8.. hold zeros)
+            scale_l = 248.0 / sum;
+            int w = on ? (int)ceil(idf_l * c * scale_l) : 0;
+            w = on && w < 1 ? 1 : w;
+            // the probed terms' largest quantised impacts in accumulator units (their bound / idf in
+            // steps of (k1+1)/255, as bm25_bounds_kernel rounds)
+            const double im = probed ? (idf_l > 0.0 ? ceil(ubt / idf_l * (255.0 / (k1 + 1.0))) + 1.0 : 255.0) : 0.0;
+            dm_l = probed ? w * (im > 255.0 || !(im >= 0.0) ? 255 : (int)im) : 0;
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) dm_l += __shfl_xor(dm_l, o, WAVE);
+            if (lane < 8) {
+                L.t_lo[lane] = lo + start;
+                L.t_len[lane] = (on && !probed) ? end - start : 0;
+                L.t_cur[lane] = 0;
+                L.t_idf[lane] = idf_l;
+                L.t_row[lane] = row_l;
+                L.t_w[lane] = w;
+            }
+        }
+        const double acc_scale = __shfl(scale_l, 0, WAVE);
+        const uint32_t dmaxq = (uint32_t)__shfl(dm_l, 0, WAVE);
+        ww_sync();
+        WW_T(0);
+        WW_C(10, 1);
+        // the wave's top-k
+        for (int i = lane; i < WW_CAP; i += 64) {
+            L.b_s[i] = -INFINITY;
+            L.b_id[i] = INT32_MAX;
+        }
+        int b_cnt = 0;                 // (uniform)
+        double th_s = -INFINITY;       // this item's k-th best so far (exact after a cut)
+        int32_t th_id = INT32_MAX;
+        double thg = -INFINITY;        // the query's other slices' threshold
+        {
+            const unsigned long long g0 = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g0) thg = dkey_inv(g0);
+        }
+        int remaining = 0;
+        for (int t = 0; t < nt; ++t) remaining += L.t_len[t];
+        ww_sync();
+        auto thq_now = [&]() -> uint32_t {   // the threshold in accumulator units (0: none yet)
+            double th = th_s > thg ? th_s : thg;
+            if (!(th > -INFINITY)) return 0u;
+            const double tq = floor(th * acc_scale * (1.0 - 1e-12));
+            return tq < 0.0 ? 0u : tq > 70000.0 ? 70000u : (uint32_t)tq;
+        };
+        // cut the buffer back to the best k: exact sort, so the threshold is the k-th best itself
+        auto cut = [&]() {
+            WW_C(12, 1);
+            ww_sync();
+            ww_sort(L.b_s, L.b_id, lane);
+            if (b_cnt > k) {
+                for (int i = k + lane; i < WW_CAP; i += 64) {
+                    L.b_s[i] = -INFINITY;
+                    L.b_id[i] = INT32_MAX;
+                }
+                b_cnt = k;
+            }
+            ww_sync();
+            if (b_cnt >= k) {
+                th_s = L.b_s[k - 1];
+                th_id = L.b_id[k - 1];
+                if (lane == 0 && th_s > -INFINITY) atomicMax(&theta_glob[q], (unsigned long long)dkey(th_s));
+            }
+        };
+        auto push = [&](bool ok, double sc, int32_t d) {
+            // (precondition: b_cnt <= 64)
+            ok = ok && !(sc < thg) && better(sc, (int64_t)d, th_s, (int64_t)th_id);
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const int p = b_cnt + __popcll(m & lt_mask);
+                L.b_s[p] = sc;
+                L.b_id[p] = d;
+            }
+            b_cnt += __popcll(m);
+            if (b_cnt > 64) cut();
+        };
+        // a probed term's contribution to doc d, 0 when the doc does not hold it
+        auto probe_add = [&](int e, int32_t d, double dl, double& score) {
+            const int tfd = (int)dense_tf[L.t_row[e] + d];
+            if (tfd > 0) score = __dadd_rn(score, bm25_contrib(L.t_idf[e], (double)tfd, dl, avgdl, k1, b));
+        };
+
+        while (remaining > 0) {
+            // ---- stage: equal quotas over the lists with postings left ----
+            int n_live = 0;
+            for (int t = 0; t < nt; ++t) n_live += L.t_len[t] - L.t_cur[t] > 0 ? 1 : 0;
+            const int quota = WW_STAGE / n_live;
+            if (lane == 0) {
+                int off = 0;
+                for (int t = 0; t < nt; ++t) {
+                    const int rem = L.t_len[t] - L.t_cur[t];
+                    const int stg = rem < quota ? rem : quota;
+                    L.t_off[t] = off;
+                    L.t_stg[t] = stg;
+                    off += stg;
+                }
+            }
+            ww_sync();
+            for (int t = 0; t < nt; ++t) {
+                const int stg = L.t_stg[t];
+                const int32_t* src = post_doc + L.t_lo[t] + L.t_cur[t];
+                const uint8_t* srci = post_imp + L.t_lo[t] + L.t_cur[t];
+                int32_t* dst = L.st_doc + L.t_off[t];
+                uint8_t* dsti = L.st_imp + L.t_off[t];
+                for (int i = lane; i < stg; i += 64) {
+                    dst[i] = src[i];
+                    dsti[i] = srci[i];
+                }
+            }
+            // the other slices' threshold travels with the staging loads
+            {
+                const unsigned long long g1 = __hip_atomic_load(&theta_glob[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g1) {
+                    const double g = dkey_inv(g1);
+                    thg = g > thg ? g : thg;
+                }
+            }
+            ww_sync();
+            // d_hi: one past the last doc every list has fully staged
+            int64_t d_hi = INT64_MAX;
+            for (int t = 0; t < nt; ++t) {
+                const int stg = L.t_stg[t];
+                if (stg > 0 && L.t_cur[t] + stg < L.t_len[t]) {
+                    const int64_t e = (int64_t)L.st_doc[L.t_off[t] + stg - 1] + 1;
+                    d_hi = e < d_hi ? e : d_hi;
+                }
+            }
+            if (lane < nt) {
+                const int stg = L.t_stg[lane];
+                L.t_sub[lane] = d_hi == INT64_MAX ? stg : count_below(L.st_doc + L.t_off[lane], stg, d_hi);
+            }
+            ww_sync();
+            int total = 0, live = 0;
+            for (int t = 0; t < nt; ++t) {
+                total += L.t_sub[t];
+                live += L.t_sub[t] > 0 ? 1 : 0;
+            }
+            WW_T(1);
+            WW_C(11, 1);
+            WW_C(14, total);
+            // ---- Bloom bits (only with postings from more than one list) ----
+            const bool bits = live > 1;
+            int bwords = WW_BLOOM;   // per list: the largest power of two that fits `live` times
+            while (bits && bwords * live > WW_BLOOM) bwords >>= 1;
+            const int bl2 = 31 - __clz(bwords * 32);
+            if (bits) {
+                if (lane == 0) {
+                    int s_ = 0;
+                    for (int t = 0; t < nt; ++t) L.t_bs[t] = L.t_sub[t] > 0 ? s_++ : -1;
+                }
+                for (int i = lane; i < WW_BLOOM; i += 64) L.bloom[i] = 0u;
+                ww_sync();
+                for (int t = 0; t < nt; ++t) {
+                    const int sub = L.t_sub[t], off = L.t_off[t], bs = L.t_bs[t];
+                    for (int i = lane; i < sub; i += 64) {
+                        const uint32_t dd = (uint32_t)L.st_doc[off + i];
+                        const uint32_t h = (dd * 2654435761u) >> (32 - bl2), h2 = (dd * 0x85EBCA6Bu + 0x9E3779B9u) >> (32 - bl2);
+                        atomicOr(&L.bloom[bs * bwords + (h >> 5)], 1u << (h & 31));
+                        atomicOr(&L.bloom[bs * bwords + (h2 >> 5)], 1u << (h2 & 31));
+                    }
+                }
+                ww_sync();
+            }
+            WW_T(2);
+            // ---- classify and score ----
+            int n_list = 0, n_work = 0;   // (uniform) singles from the front, postings to search from the back
+            // the listed singles [0, n_list): gathers, float64 score, push -- 64 at a time
+            auto score_listed = [&]() {
+                WW_T(3);
+                WW_C(13, (n_list + 63) / 64);
+                WW_C(15, n_list);
+                for (int base = 0; base < n_list; base += 64) {
+                    const int j = base + lane;
+                    bool ok = j < n_list;
+                    double score = 0.0;
+                    int32_t d = 0;
+                    if (ok) {
+                        const int idx = L.list[j];
+                        int t = 0;
+                        while (t + 1 < nt && idx >= L.t_off[t + 1]) ++t;   // (offsets ascend with t; an empty list shares the next one's)
+                        d = L.st_doc[idx];
+                        if (qc != -1 && doc_coll[d] != qc) ok = false;
+                        if (ok) {
+                            const double dl = (double)doclen[d];
+                            const double tf_own = (double)post_tf[L.t_lo[t] + L.t_cur[t] + (idx - L.t_off[t])];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                if (e >= nt) continue;
+                                if (L.t_row[e] >= 0) probe_add(e, d, dl, score);
+                                else if (e == t) score = __dadd_rn(score, bm25_contrib(L.t_idf[e], tf_own, dl, avgdl, k1, b));
+                            }
+                        }
+                    }
+                    push(ok, score, d);
+                }
+                n_list = 0;
+                WW_T(4);
+            };
+            for (int t = 0; t < nt; ++t) {
+                const int sub = L.t_sub[t];
+                if (sub == 0) continue;
+                const int off = L.t_off[t];
+                const uint32_t wt = (uint32_t)L.t_w[t];
+                const uint8_t* imp_t = L.st_imp + off;
+                for (int base = 0; base < sub; base += 64) {
+                    const int i = base + lane;
+                    const uint32_t thq = thq_now();
+                    bool alone = i < sub, search = false;
+                    if (alone) {
+                        const int32_t d = L.st_doc[off + i];
+                        if (bits) {   // two bits per (list, doc): ~5 % false positives where one bit gave 12 %
+                            const uint32_t dd = (uint32_t)d;
+                            const uint32_t h = (dd * 2654435761u) >> (32 - bl2), h2 = (dd * 0x85EBCA6Bu + 0x9E3779B9u) >> (32 - bl2);
+                            const uint32_t w = h >> 5, bit = 1u << (h & 31), w2 = h2 >> 5, bit2 = 1u << (h2 & 31);
+                            for (int e = 0; e < nt; ++e) {
+                                const int bs = L.t_bs[e];
+                                if (e != t && bs >= 0 && (L.bloom[bs * bwords + w] & bit) && (L.bloom[bs * bwords + w2] & bit2)) search = true;
+                            }
+                        }
+                        alone = !search;
+                        if (alone && thq != 0u && (uint32_t)imp_t[i] * wt + dmaxq < thq) alone = false;   // cannot enter
+                    }
+                    const unsigned long long ma = __ballot(alone), ms = __ballot(search);
+                    if (alone) L.list[n_list + __popcll(ma & lt_mask)] = (uint16_t)(off + i);
+                    if (search) L.list[WW_STAGE - 1 - (n_work + __popcll(ms & lt_mask))] = (uint16_t)(off + i);
+                    n_list += __popcll(ma);
+                    n_work += __popcll(ms);
+                    // no threshold yet: score what is listed as soon as it can fill the top-k, so that
+                    // the rest of the pass is classified against a threshold
+                    ww_sync();
+                    if (n_list >= 64 && (thq_now() == 0u || n_list + n_work + 64 > WW_STAGE)) score_listed();
+                }
+            }
+            ww_sync();
+            score_listed();
+            WW_T(3);
+            // the postings whose doc may be in another list: owner and positions by search
+            for (int base = 0; base < n_work; base += 64) {
+                const int j = base + lane;
+                bool ok = j < n_work;
+                double score = 0.0;
+                int32_t d = 0;
+                if (ok) {
+                    const int idx = L.list[WW_STAGE - 1 - j];
+                    int t = 0;
+                    while (t + 1 < nt && idx >= L.t_off[t + 1]) ++t;
+                    d = L.st_doc[idx];
+                    int wf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        wf[e] = -1;
+                        if (e < nt && L.t_sub[e] > 0)
+                            wf[e] = e == t ? idx - L.t_off[e] : find_doc(L.st_doc + L.t_off[e], L.t_sub[e], d);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < t && wf[e] >= 0) ok = false;             // an earlier list owns the doc
+                    if (ok && qc != -1 && doc_coll[d] != qc) ok = false;
+                    if (ok) {
+                        const double dl = (double)doclen[d];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (e >= nt) continue;
+                            if (L.t_row[e] >= 0) probe_add(e, d, dl, score);
+                            else if (wf[e] >= 0)
+                                score = __dadd_rn(score, bm25_contrib(L.t_idf[e], (double)post_tf[L.t_lo[e] + L.t_cur[e] + wf[e]], dl, avgdl, k1, b));
+                        }
+                    }
+                }
+                push(ok, score, d);
+            }
+            ww_sync();
+            if (lane == 0)
+                for (int t = 0; t < nt; ++t) L.t_cur[t] += L.t_sub[t];
+            remaining -= total;
+            ww_sync();
+            WW_T(5);
+        }
+        // ---- the item's list: sorted best first ----
+        ww_sync();
+        ww_sort(L.b_s, L.b_id, lane);
+        const int n = b_cnt < k ? b_cnt : k;
+        if (S == 1) {   // the query's only item: its list is the result
+            for (int i = lane; i < k; i += 64) {
+                out_s[(int64_t)q * k + i] = i < n ? L.b_s[i] : -INFINITY;
+                out_id[(int64_t)q * k + i] = i < n ? (int64_t)L.b_id[i] + id_base : -1;
+            }
+            if (lane == 0) out_cnt[q] = n;
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                slice_s[(int64_t)item * k + i] = L.b_s[i];
+                slice_id[(int64_t)item * k + i] = (int64_t)L.b_id[i] + id_base;
+            }
+            if (lane == 0) {
+                slice_cnt[item] = n;
+                if (n >= k) atomicMax(&theta_glob[q], (unsigned long long)dkey(L.b_s[k - 1]));
+            }
+        }
+        ww_sync();
+        WW_T(6);
+    }
+#ifdef BM_STAMPS
+    WW_T(8);
+    if (lane == 0) {
+        const int w = blockIdx.x * WW_WAVES + (threadIdx.x >> 6);
+        for (int i = 0; i < 16; ++i) wstamps[(size_t)w * 16 + i] = ws_acc[i];
+    }
+#endif
+#undef WW_T
+#undef WW_C
+}
+
 // Between stage A and stage B: the sweeps that are still needed.  The docs of a sweep hold none of
 // the query's other terms, so a score there is at most the sum of the dense terms' bounds (added
 // out of order: hence the margin); stage A is complete, and when that sum stays below its
@@ -1336,7 +1870,7 @@ __global__ __launch_bounds__(FILTER_THREADS) void bm25_sweep_filter_kernel(
     auto item_of = [&](int q, int s) -> int { return s == 0 ? q : q_item0[q] + s; };
     auto sweeps = [&](int q) -> bool {   // (and closes the slices of a sweep that is ruled out)
         const int SA = q_SA[q];
-        if (SA < 0) return false;
+        if (SA < 0 || SA == q_S[q]) return false;   // not split / walked by waves without a stage B
         const unsigned long long g = theta_glob[q];
         if (g && q_dub[q] * (1.0 + 1e-12) < dkey_inv(g)) {
             // (a threshold exists: the query has stage-A slices, the lists are merged)
@@ -1826,8 +2360,8 @@ __global__ __launch_bounds__(BMM_THREADS) void bm25_merge_kernel(
 // ---- workspace of thr_bm25_topk ----
 struct BmLayout {
     size_t off_ctl, off_theta, off_tot, off_dub, off_sweep, off_nt, off_S, off_SA, off_pmask, off_item0, off_long, off_qterms, off_items,
-        off_ipos, off_ss, off_sid, off_scnt, off_stamps, total;
-    int cap;
+        off_ipos, off_wrec, off_wterm, off_ss, off_sid, off_scnt, off_stamps, total;
+    int cap, cap_base;
 };
 static BmLayout bm_layout(int nq, int mt, int k) {
     BmLayout L;
@@ -1836,14 +2370,17 @@ static BmLayout bm_layout(int nq, int mt, int k) {
         const char* ev = getenv("THR_BM25_ITEMS");   // item slots beyond two per query (A/B knob)
         extra = ev && atoi(ev) >= 1024 ? atoi(ev) : BM_EXTRA_ITEMS;
     }
-    L.cap = 2 * nq + extra;   // (a query with dense terms is at least two items: stage A, stage B)
+    // (a query with dense terms is at least two items: stage A, stage B; the wave walk cuts stage A
+    // into ~1 K-posting slices: 16 K more items for them)
+    L.cap_base = 2 * nq + extra;
+    L.cap = L.cap_base + BM_WAVE_ITEMS;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    L.off_ctl = take(sizeof(int32_t) * 8);                 // [0] items, [1] [2] [4] next item of a kernel, [3] queries with dense terms, [5] sweeps, [6] plan workgroups done  } zeroed
+    L.off_ctl = take(sizeof(int32_t) * 16);                 // [0] items, [1] [2] [4] next item of a kernel, [3] queries with dense terms, [5] sweeps, [6] plan workgroups done, [7] stage-A slice size, [8] queries of the workgroup walk  } zeroed
     L.off_theta = take(sizeof(unsigned long long) * nq);   // shared thresholds (keys)   } per call
     L.off_tot = take(sizeof(int64_t) * nq);
     L.off_dub = take(sizeof(double) * nq);
@@ -1857,6 +2394,8 @@ static BmLayout bm_layout(int nq, int mt, int k) {
     L.off_items = take(sizeof(int2) * (size_t)L.cap);
     L.off_sweep = take(sizeof(int32_t) * (size_t)L.cap);
     L.off_ipos = take(sizeof(int32_t) * 2 * (size_t)L.cap * mt);
+    L.off_wrec = take(sizeof(WwItem) * (size_t)L.cap);
+    L.off_wterm = take(sizeof(WwTerm) * (size_t)L.cap * 8);
     L.off_ss = take(sizeof(double) * (size_t)L.cap * k);
     L.off_sid = take(sizeof(int64_t) * (size_t)L.cap * k);
     L.off_scnt = take(sizeof(int32_t) * (size_t)L.cap);
@@ -1977,6 +2516,8 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int32_t* q_terms = (int32_t*)(ws + L.off_qterms);
     int2* items = (int2*)(ws + L.off_items);
     int32_t* ipos = (int32_t*)(ws + L.off_ipos);
+    WwItem* wrec = (WwItem*)(ws + L.off_wrec);
+    WwTerm* wterm = (WwTerm*)(ws + L.off_wterm);
     double* slice_s = (double*)(ws + L.off_ss);
     int64_t* slice_id = (int64_t*)(ws + L.off_sid);
     int32_t* slice_cnt = (int32_t*)(ws + L.off_scnt);
@@ -1985,12 +2526,14 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
 #ifdef BM_STAMPS
     hipMemsetAsync(ws + L.off_stamps, 0, sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap), st);
 #endif
-    static int small = -1, use_dense = 1, walk_div = 64, fuse_div = 8;
+    static int small = -1, use_dense = 1, walk_div = 64, fuse_div = 8, use_wave = 1;
     if (small < 0) {
         const char* ei = getenv("THR_BM25_DENSE");    // 0: every term through its postings (A/B knob)
         use_dense = !(ei && ei[0] == '0');
         ei = getenv("THR_BM25_WALK_DIV");             // a term with rows may be walked when held by < 1/this of the docs
         if (ei && atoi(ei) > 0) walk_div = atoi(ei);
+        ei = getenv("THR_BM25_WALK");                 // b(lock): stage A on the workgroup walk (the round-3 path; A/B knob)
+        use_wave = !(ei && ei[0] == 'b');
         ei = getenv("THR_BM25_FUSE_DIV");             // one launch for ordinary items + stage A from 1/this of the queries (0: never)
         if (ei && atoi(ei) >= 0) fuse_div = atoi(ei);
         const char* ev = getenv("THR_BM25_SHAPE");
@@ -2001,14 +2544,19 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int grid = bm_num_cus() * (huge ? 1 : big ? 2 : 4);
     if (grid > L.cap) grid = L.cap;
     const int32_t* dslot = use_dense ? dense_slot : nullptr;
+    // OR queries of <= 8 terms by waves (bm25_walk_wave_kernel) when the impacts are there and k fits a
+    // wave's buffer; AND queries, longer ones and calls without bounds keep the workgroup walk
+    const bool wave = use_wave && k <= 64 && term_ub != nullptr && post_imp != nullptr && !conjunctive;
     int plan_blocks = (n_queries + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_blocks = plan_blocks > PLAN_MAX_BLOCKS ? PLAN_MAX_BLOCKS : plan_blocks;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(plan_blocks), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap, conjunctive, grid, BM_TARGET0, walk_div, dslot, term_ub, n_docs, ctl,
+                       n_queries, max_terms, L.cap_base, BM_WAVE_ITEMS, conjunctive, grid, BM_TARGET0, wave ? WW_TARGET : 0, wave ? 1 : 0, walk_div, dslot, term_ub, n_docs, ctl,
                        q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
-                       rowptr, post_doc, ctl, q_nt, q_S, q_SA, q_long, q_terms, items, max_terms, q_pmask, n_docs, ipos);
+                       rowptr, post_doc, ctl, q_nt, q_S, q_SA, q_long, q_terms, items, max_terms, q_pmask, n_docs, ipos,
+                       idf, term_ub, dslot, dense_stride, query_coll, wave ? wrec : (WwItem*)nullptr,
+                       wave ? wterm : (WwTerm*)nullptr);
     int rc = launch_status();
     if (rc) return rc;
 #ifdef BM_STAMPS
@@ -2029,7 +2577,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                        term_ub ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
                        avgdl, k1, b,                                                                \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, n_queries,         \
-                       dslot ? fuse_div : 0, ctl, q_nt, q_S,                                        \
+                       wave ? -1 : dslot ? fuse_div : 0, ctl, q_nt, q_S,                            \
                        q_SA, q_pmask, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt,    \
                        out_scores, out_ids, out_counts BM_STAMP_ARG(DP))
 #define THR_BM25_LAUNCH_SHAPE(DP)                                                                     \
@@ -2038,14 +2586,49 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         else if (big) THR_BM25_LAUNCH(512, 8192, 4096, 1024, DP);                                     \
         else THR_BM25_LAUNCH(256, 4096, 2048, 512, DP);                                               \
     } while (0)
-    if (dslot) {
-        // queries with dense terms: stage A (their other terms' postings, the dense rows probed), then
-        // stage B (doc-window sweeps, skipped where stage A's threshold rules them out).  Every kernel
-        // walks the one item list and takes the items that are its own.
-        // (of these two and the ordinary launch further down, the kernels themselves pick who works:
-        // the fused one when many of the batch's queries hold dense terms, else the two others)
+    // The walks.  Wave mode: every OR query of <= 8 terms -- stage A of the ones with probed terms and
+    // the ones without -- is the wave kernel's; the workgroup walk further down takes what is left
+    // (nothing, usually).  Else: queries with dense terms are stage A of the workgroup walk (fused with
+    // the ordinary items, or on its own: the kernels themselves pick who works), the rest ordinary items.
+    if (wave) {
+        int wgrid_w = bm_num_cus() * 4;   // sixteen waves per CU; a small batch has no use for thousands of waves
+        if ((long long)n_queries * 32 + 32 < wgrid_w) wgrid_w = n_queries * 32 + 32;
+        hipLaunchKernelGGL(bm25_walk_wave_kernel, dim3(wgrid_w), dim3(WW_WAVES * 64), 0, st, rowptr, post_doc,
+                           post_tf, doclen, idf, term_ub, post_imp, dslot, dense_tf, dense_stride, avgdl, k1, b,
+                           id_base, max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S, q_SA, q_pmask, q_terms,
+                           items, ipos, wrec, wterm, theta, slice_s, slice_id, slice_cnt, out_scores, out_ids, out_counts
+#ifdef BM_STAMPS
+                           , (unsigned long long*)(ws + L.off_stamps)
+#endif
+                           );
+#ifdef BM_STAMPS
+        {
+            hipStreamSynchronize(st);
+            const int nw = wgrid_w * WW_WAVES;
+            std::vector<unsigned long long> h((size_t)nw * 16);
+            hipMemcpy(h.data(), ws + L.off_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double tot[16] = {0};
+            double mx = 0;
+            for (int w = 0; w < nw; ++w) {
+                double all = 0;
+                for (int i = 0; i < 16; ++i) tot[i] += (double)h[(size_t)w * 16 + i];
+                for (int i = 0; i < 9; ++i) all += (double)h[(size_t)w * 16 + i];
+                mx = all > mx ? all : mx;
+            }
+            static const char* nm[9] = {"set-up", "stage+d_hi", "bloom", "classify", "score listed", "work list+advance", "finish", "skipped items", "idle tail"};
+            double all = 0;
+            for (int i = 0; i < 9; ++i) all += tot[i];
+            fprintf(stderr, "[bm25 wave walk] %d waves, %.0f cycles per wave (max %.0f):", nw, all / nw, mx);
+            for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / all);
+            fprintf(stderr, " | items %.0f passes %.0f cuts %.0f batches %.0f postings %.0f listed %.0f\n", tot[10], tot[11], tot[12], tot[13], tot[14], tot[15]);
+        }
+#endif
+    } else if (dslot) {
         THR_BM25_LAUNCH_SHAPE(2);
         THR_BM25_LAUNCH_SHAPE(1);
+    }
+    if (dslot) {
+        // stage B: doc-window sweeps, skipped where stage A's threshold rules them out
         if ((rc = launch_status())) return rc;
         hipLaunchKernelGGL(bm25_sweep_filter_kernel, dim3(1), dim3(FILTER_THREADS), 0, st, ctl, n_queries, q_S,
                            q_SA, q_item0, q_dub, theta, slice_cnt, sweep_items);
