@@ -323,7 +323,11 @@ def test_bm25_small_block_shape_in_a_subprocess():
 
 
 @pytest.mark.parametrize("knobs", ["THR_BM25_DENSE=0", "THR_BM25_WALK_DIV=8 THR_BM25_ITEMS=1024 THR_BM25_FUSE_DIV=0",
-                                   "THR_BM25_SHAPE=small THR_BM25_DENSE_SHARE=0.05 THR_BM25_FUSE_DIV=1000000"])
+                                   "THR_BM25_SHAPE=small THR_BM25_DENSE_SHARE=0.05 THR_BM25_FUSE_DIV=1000000",
+                                   # the workgroup walk for every query (round 3's path; the default since
+                                   # round 4 gives OR queries of <= 8 terms to bm25_walk_wave_kernel), its
+                                   # stage A on a launch of its own / fused with the ordinary items
+                                   "THR_BM25_WALK=block THR_BM25_FUSE_DIV=0", "THR_BM25_WALK=block"])
 def test_bm25_dense_row_knobs_in_a_subprocess(knobs):
     """The A/B knobs around the dense-term rows change the cost, never the result: without the rows
     in the kernels (THR_BM25_DENSE=0), with nearly every row term walked and the fewest work items

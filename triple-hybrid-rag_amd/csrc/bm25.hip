@@ -1617,15 +1617,17 @@ __global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
         };
 
         while (remaining > 0) {
-            // ---- stage: equal quotas over the lists with postings left ----
-            int n_live = 0;
-            for (int t = 0; t < nt; ++t) n_live += L.t_len[t] - L.t_cur[t] > 0 ? 1 : 0;
-            const int quota = WW_STAGE / n_live;
+            // ---- stage: the stage is shared out in proportion to what is left of each list (a slice is
+            // cut at docs of its longest list: equal quotas would take a 900 + 100 slice in two passes) ----
             if (lane == 0) {
+                int n_live = 0;
+                for (int t = 0; t < nt; ++t) n_live += L.t_len[t] - L.t_cur[t] > 0 ? 1 : 0;
+                const int spare = WW_STAGE - 16 * n_live;   // every list with postings left gets at least 16 slots
                 int off = 0;
                 for (int t = 0; t < nt; ++t) {
                     const int rem = L.t_len[t] - L.t_cur[t];
-                    const int stg = rem < quota ? rem : quota;
+                    int stg = rem > 0 ? 16 + (int)((int64_t)spare * rem / remaining) : 0;
+                    stg = stg < rem ? stg : rem;
                     L.t_off[t] = off;
                     L.t_stg[t] = stg;
                     off += stg;
