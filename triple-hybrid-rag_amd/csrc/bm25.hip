@@ -181,6 +181,7 @@ constexpr int BM_MAX_SLICES = 128;
 constexpr int BW_PAD = 65536;          // docs per window of bm25_window_kernel = zero padding of a dense row
 constexpr int BM_EXTRA_ITEMS = 16384;  // item list capacity = 2 * n_queries + this (8 K / 16 K / 32 K / 64 K measured on 256 and
                                        // 2048 stop-word queries: 0.95 / 0.86 / 0.85 / 0.86 and 2.07 / 1.90 / 1.94 / 2.19 ms)
+constexpr int WW_TARGET_MIN = 640, WW_TARGET_MAX = 1536;   // postings per slice of the wave walk (bm25_walk_wave_kernel)
 constexpr int BM_TARGET0 = 24576;      // postings per slice aimed at when the batch fills the grid (3 passes)
 constexpr int BM_TARGET_MIN = 8192;    // ... and at least (one pass), when it does not: a one-query
                                        // call spreads its 75 K postings over nine workgroups
@@ -349,24 +350,36 @@ __global__ __launch_bounds__(PLAN_THREADS) void bm25_plan_kernel(
     const int q0 = threadIdx.x * per < nq ? threadIdx.x * per : nq;
     const int q1 = q0 + per < nq ? q0 + per : nq;
     // slice size: what gives every workgroup slot of the grid an item, between one pass and three
-    __shared__ long long red64[PLAN_THREADS];
+    __shared__ long long red64[PLAN_THREADS], red64w[PLAN_THREADS];
     {
-        long long t = 0;   // (a stage-B sweep counts one unit per doc)
+        long long t = 0, tw = 0;   // (a stage-B sweep counts one unit per doc)
         for (int q = q0; q < q1; ++q) {
             const long long v = tot_of(q);
             t += v >= 0 ? v : -v - 1 + n_docs;
+            tw += v >= 0 ? (wave_q_of(q) ? v : 0) : -v - 1;   // postings the waves will walk
         }
         red64[threadIdx.x] = t;
+        red64w[threadIdx.x] = tw;
         __syncthreads();
         for (int o = PLAN_THREADS / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red64[threadIdx.x] += red64[threadIdx.x + o];
+            if ((int)threadIdx.x < o) {
+                red64[threadIdx.x] += red64[threadIdx.x + o];
+                red64w[threadIdx.x] += red64w[threadIdx.x + o];
+            }
             __syncthreads();
         }
     }
     long long target = red64[0] / (n_slots > 0 ? n_slots : 1);
     target = target < BM_TARGET_MIN ? BM_TARGET_MIN : target > target_max ? target_max : target;
-    // stage-A slices have their own size when a wave, not a workgroup, takes one (bm25_walk_wave_kernel)
-    long long target_a = target_a0 > 0 ? target_a0 : target;
+    // The waves' slices have their own size (bm25_walk_wave_kernel): what gives each of the ``target_a0``
+    // wave slots of the chip an item, between WW_TARGET_MIN (a small batch spreads over many waves: 256
+    // survey queries 0.46 -> 0.43 ms) and WW_TARGET_MAX (a full batch pays the per-item set-up less
+    // often: 2048 survey queries 0.89 -> 0.87 ms); 0: no wave walk, stage A takes the shared size.
+    long long target_a = target;
+    if (target_a0 > 0) {
+        target_a = red64w[0] / target_a0;
+        target_a = target_a < WW_TARGET_MIN ? WW_TARGET_MIN : target_a > WW_TARGET_MAX ? WW_TARGET_MAX : target_a;
+    }
     // ``cap`` items for the sweeps and the workgroup walk's items (the slice size that budget gives them
     // was tuned with it), ``cap_wave`` more for the waves' ~1 K-posting slices
     __shared__ int red_w[PLAN_THREADS];
@@ -1422,7 +1435,6 @@ constexpr int WW_WAVES = 4;        // waves per workgroup (independent: they nev
 constexpr int WW_STAGE = 1024;     // doc ids a wave stages per pass
 constexpr int WW_CAP = 128;        // top-k slots of a wave (k <= 64: a batch of 64 always fits after a cut)
 constexpr int WW_BLOOM = 256;      // words of Bloom bits per wave, shared out among the lists with postings
-constexpr int WW_TARGET = 1024;    // postings per stage-A slice the plan aims at
 constexpr int BM_WAVE_ITEMS = 16384;   // item slots for the waves' slices, on top of the list's capacity
 
 struct WwLds {
@@ -2552,7 +2564,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     int plan_blocks = (n_queries + PLAN_THREADS - 1) / PLAN_THREADS;
     plan_blocks = plan_blocks > PLAN_MAX_BLOCKS ? PLAN_MAX_BLOCKS : plan_blocks;
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(plan_blocks), dim3(PLAN_THREADS), 0, st, rowptr, n_vocab, query_terms,
-                       n_queries, max_terms, L.cap_base, BM_WAVE_ITEMS, conjunctive, grid, BM_TARGET0, wave ? WW_TARGET : 0, wave ? 1 : 0, walk_div, dslot, term_ub, n_docs, ctl,
+                       n_queries, max_terms, L.cap_base, BM_WAVE_ITEMS, conjunctive, grid, BM_TARGET0, wave ? bm_num_cus() * 4 * WW_WAVES : 0, wave ? 1 : 0, walk_div, dslot, term_ub, n_docs, ctl,
                        q_tot, q_dub, q_nt, q_S, q_SA, q_pmask, q_item0, q_long, q_terms, items);
     const int64_t edge_threads = (int64_t)L.cap * max_terms;
     hipLaunchKernelGGL(bm25_edges_kernel, dim3((unsigned)((edge_threads + 255) / 256)), dim3(256), 0, st,
