@@ -240,7 +240,12 @@ int thr_bm25_bounds(const int64_t *rowptr, const int32_t *post_doc, const int32_
  * persistent grid, the slices of a query share the pruning threshold through a device-side
  * atomic max and are merged at the end -- a stop-word query is the job of many workgroups, not
  * of one.  ``workspace`` >= thr_bm25_workspace_bytes(n_queries, max_terms, k): item list, slice
- * edges, per-slice lists. */
+ * edges, per-slice lists.
+ * Wave walk (round 4, same ABI): with the bounds and impacts given, k <= 64 and the OR form, every
+ * query of <= 8 terms is cut into slices of ~640-1536 postings instead and ONE WAVE walks a slice
+ * (bm25_walk_wave_kernel: no workgroup barrier, sixteen waves -- sixteen independent latency chains --
+ * per CU); queries of more terms, AND queries, k > 64 and calls without bounds keep the workgroup walk.
+ * Same arithmetic, same bounds: the same bits either way (THR_BM25_WALK=block forces the latter). */
 /* Dense terms (ABI 7).  A stop word's posting list is most of the corpus; walking it posting by
  * posting is the slowest way to learn that nearly all of its docs cannot make the top-k.  The
  * caller picks the terms held by a large share of the docs (the host layer: df >= 1 % of the
