@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define THR_ABI_VERSION 8
+#define THR_ABI_VERSION 9
 
 typedef void *thr_stream_t;
 
@@ -163,6 +163,42 @@ int thr_dense_topk_f16(const float *docs, const uint16_t *docs16 /* or NULL */, 
                        double *out_scores, int64_t *out_ids, int32_t *out_counts,
                        uint32_t *out_flags, void *workspace, size_t workspace_bytes,
                        thr_stream_t stream);
+/* e1  The same search split around ONE exchange between document shards (ABI 9): what a shard of G
+ * does NOT have to rescore.  The reference has a single table and a single `ORDER BY ... LIMIT k`
+ * (rag2_schema.sql:404-410); sharded, every shard would rescore its own k best although only
+ * about k / G of them are among the k best of all.
+ *   thr_dense_shortlist_f16  thr_dense_topk_f16 up to and including the filter scan (the candidate
+ *                            lists stay in ``workspace``), then per query the ``m`` largest scan
+ *                            scores, each lowered by the scan's error bound to a LOWER bound of
+ *                            ||q|| x cosine of its row: top_lb float32 [n_queries, m], -inf padded;
+ *   (exchange)               all-gather top_lb over the shards -> [G, n_queries, m];
+ *   thr_dense_floor          gfloor[q] = the k-th largest of a query's G * m values (-inf when
+ *                            fewer than k are finite): a lower bound of ||q|| x the k-th best
+ *                            cosine of the whole corpus;
+ *   thr_dense_finish_f16     the rest of thr_dense_topk_f16 on the SAME workspace and arguments:
+ *                            rows whose scan score is below gfloor[q] - 1.5 eps ||q|| are left out
+ *                            of the float64 rescoring.  A shard's list may then hold FEWER than k
+ *                            rows (out_counts); THR_FLAG_CERTIFIED now says "no row outside this
+ *                            list can be among the k best of all shards" (proved against the
+ *                            shard's own k-th score or against gfloor), and thr_dense_rescue
+ *                            redoes the others exhaustively as before.  thr_merge_topk over the
+ *                            shards' lists is then the exact top-k: no second exchange.
+ * gfloor == NULL (or -inf entries) gives thr_dense_topk_f16's behaviour.  m <= THR_DENSE_MAX_K,
+ * G * m <= 8192; choose m >= k / G, about 2 k / G for a floor close to the true k-th score. */
+int thr_dense_shortlist_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
+                            const float *inv_norm, int64_t n_docs, int dim, const float *queries,
+                            int n_queries, int kprime, const int32_t *doc_coll,
+                            const int32_t *query_coll, int m, float *top_lb /* [nq, m] */,
+                            void *workspace, size_t workspace_bytes, thr_stream_t stream);
+int thr_dense_floor(const float *top_lb /* [n_shards, nq, m] */, int n_shards, int n_queries, int m,
+                    int k, float *gfloor /* [nq] */, thr_stream_t stream);
+int thr_dense_finish_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
+                         const double *dnorm, const float *inv_norm, int64_t n_docs, int dim,
+                         int64_t id_base, const float *queries, int n_queries, int k, int kprime,
+                         const int32_t *doc_coll, const int32_t *query_coll,
+                         const float *gfloor /* [nq] or NULL */, double *out_scores,
+                         int64_t *out_ids, int32_t *out_counts, uint32_t *out_flags,
+                         void *workspace, size_t workspace_bytes, thr_stream_t stream);
 int thr_dense_scan_probe_f16(const float *docs, const uint16_t *docs16 /* or NULL */,
                              const float *inv_norm, int64_t n_docs, int dim, const float *queries,
                              int n_queries, void *workspace, size_t workspace_bytes,

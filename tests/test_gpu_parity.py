@@ -1204,6 +1204,130 @@ def test_dense_f16_shortlist_is_still_exact(T, n, d, mode):
     assert_topk_equal(S, I, cnt, Se, Ie, cnte, "dense-f16")
 
 
+def _floor_search(T, x, q, k, n_shards, shortlist="f16", coll=None, qc=None, use_floor=True):
+    """The dense channel of a document-sharded index with every shard in THIS process: shortlist on
+    every shard, the lower bounds stacked (what the all-gather delivers), thr_dense_floor, finish on
+    every shard, thr_merge_topk.  -> merged (S, I, cnt), per-shard counts [G, nq], the flags the
+    finish wrote (before any rescue) [G, nq], the rescued queries per shard, the floor [nq]."""
+    n = x.shape[0]
+    shards = []
+    for s in range(n_shards):
+        lo, hi = s * n // n_shards, (s + 1) * n // n_shards
+        idx = T.GpuIndex(doc_base=lo).set_dense(x[lo:hi], shortlist=shortlist)
+        if coll is not None:
+            idx.set_collections(coll[lo:hi])
+        shards.append(idx)
+    qd = dev(q)
+    qcd = None if qc is None else dev(qc)
+    gfloor = None
+    if use_floor:
+        lbs = torch.stack([ix.dense_shortlist(qd, k, n_shards, collections=qcd) for ix in shards])
+        assert lbs.shape == (n_shards, q.shape[0], T.index.floor_width(k, n_shards))
+        gfloor = T._native.dense_floor(lbs, k)
+    else:
+        for ix in shards:   # (the finish reads the lists a shortlist call left)
+            ix.dense_shortlist(qd, k, n_shards, collections=qcd)
+    outs = []
+    for ix in shards:
+        if not use_floor:
+            ix.dense_shortlist(qd, k, n_shards, collections=qcd)
+        outs.append(ix.dense_finish(qd, k, gfloor, collections=qcd))
+    S = torch.stack([o[0] for o in outs])
+    I = torch.stack([o[1] for o in outs])
+    Sm, Im, cm = T._native.merge_topk(S, I, k)
+    cnts = torch.stack([o[2] for o in outs]).cpu().numpy()
+    flags = torch.stack([o[3] for o in outs]).cpu().numpy()
+    nres = [int(o[4]) for o in outs]
+    return (Sm, Im, cm), cnts, flags, nres, (None if gfloor is None else gfloor.cpu().numpy())
+
+
+@pytest.mark.parametrize("n,d,nq,k,g,shortlist", [(160000, 768, 48, 100, 8, "f16"), (32000, 768, 20, 100, 8, "f16"),
+                                                  (90000, 512, 33, 10, 4, "f16"), (60000, 1024, 17, 100, 2, "f16"),
+                                                  (120000, 768, 24, 100, 8, "f16-inline")])
+def test_dense_shard_floor_rescoring_only_what_can_reach_the_global_topk(T, n, d, nq, k, g, shortlist):
+    """thr_dense_shortlist_f16 / thr_dense_floor / thr_dense_finish_f16 (thr_hip.h e1): every shard
+    sends its top-m scan scores as lower bounds, the k-th largest of all of them is a floor under
+    the GLOBAL k-th score, and a shard rescores only rows that can clear it -- about k / G instead
+    of k.  The merged lists are the oracle's top-k, bit for bit, with nothing rescued."""
+    x, rng = rand_docs(n, d, 41)
+    x[n // 3] = 0
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[:3] = x[[11, n // 2, n - 5]] + 0.3 * q[:3]
+    (S, I, cnt), cnts, flags, nres, gfloor = _floor_search(T, x, q, k, g, shortlist)
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, k)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "shard-floor")
+    assert sum(nres) == 0 and np.all(flags & 1), "every shard's list is certified by the shortlist path"
+    # the floor is a LOWER bound of ||q|| x the global k-th cosine
+    qn = np.linalg.norm(q.astype(np.float64), axis=1)
+    assert np.all(gfloor <= qn * Se[:, k - 1])
+    assert np.all(gfloor > qn * Se[:, k - 1] - 0.02 * qn), "and a close one"
+    # what it buys: the shards together rescored little more than k rows per query, not G * k
+    assert np.all(cnts.sum(0) >= k)
+    assert cnts.sum(0).mean() < 1.35 * k + 4 * g, cnts.sum(0).mean()
+    # same bits without the floor (every shard rescoring a top-k of its own)
+    (S0, I0, c0), cnts0, _, _, _ = _floor_search(T, x, q, k, g, shortlist, use_floor=False)
+    assert torch.equal(S0, S) and torch.equal(I0, I)
+    assert cnts0.sum(0).mean() >= min(g * k, 0.9 * n / g * g if n < g * k else g * k) * 0.99
+
+
+def test_dense_shard_floor_ties_nulls_skew_and_collections(T):
+    """The cases a floor could get wrong: the k best all on ONE shard (the floor from top-m values
+    is loose there, never wrong), a giant tie across shards, a shard of NULL rows, a collection
+    filter thinner than k -- each merged result equal to the oracle's."""
+    n, d, k, g = 64000, 768, 100, 8
+    x, rng = rand_docs(n, d, 43)
+    per = n // g
+    x[3 * per + 100:3 * per + 400] = x[3 * per + 99]          # 301-way tie inside shard 3
+    x[per - 50:per + 50] = x[5 * per + 7]                      # 101-way tie over shards 0, 1 (and 5)
+    x[6 * per:7 * per] = 0                                     # shard 6: no embeddings at all
+    q = rng.standard_normal((8, d)).astype(np.float32)
+    q[0] = x[3 * per + 99] * 1.5
+    q[1] = x[5 * per + 7] + 0.001 * q[1]
+    q[2] = 0
+    # skew: query 3's best 150 rows all on shard 2
+    x[2 * per + 1000:2 * per + 1150] = q[3] / np.linalg.norm(q[3]) + 0.05 * x[2 * per + 1000:2 * per + 1150]
+    (S, I, cnt), cnts, flags, nres, gfloor = _floor_search(T, x, q, k, g)
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, k)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "shard-floor-ties")
+    assert cnts[6].sum() == 0
+    # the skewed query: shard 2 holds the whole top-k but can only send its top m = 26, so the
+    # floor is the 74th best of the OTHER shards' rows -- loose (they rescore ~80 rows for nothing)
+    # and still far from G * k
+    assert cnts[2, 3] == k and k < cnts[:, 3].sum() < 2 * k
+    # collections: 2 % ones (thinner than k on a shard: its list is everything it has of them)
+    coll = (np.arange(n) * 7919 % 50).astype(np.int32)
+    qc = np.array([7, -1, 7, 3, 12345, 11, -1, 49], dtype=np.int32)
+    (S, I, cnt), cnts, flags, nres, _ = _floor_search(T, x, q, k, g, coll=coll, qc=qc)
+    S, I, cnt = S.cpu().numpy(), I.cpu().numpy(), cnt.cpu().numpy()
+    dn = O.doc_norms_f64(x)
+    for i in range(8):
+        sc = O.cosine_scores_f64(x, q[i], dn)
+        if qc[i] != -1:
+            sc[coll != qc[i]] = -np.inf
+        ts, ti = O.topk_desc(sc, k)
+        assert cnt[i] == len(ti) and np.array_equal(I[i, :len(ti)], ti), (i, qc[i])
+        assert np.array_equal(S[i, :len(ti)], ts)
+    assert cnt[4] == 0
+
+
+def test_dense_floor_kernel_known_answers(T):
+    """thr_dense_floor alone: k-th largest of the shards' values, duplicates counted, -inf when
+    fewer than k are finite."""
+    rng = np.random.default_rng(5)
+    for g, m, nq, k in ((8, 16, 33, 100), (2, 100, 7, 100), (3, 16, 5, 50), (1, 16, 4, 10), (64, 128, 3, 128)):
+        v = rng.standard_normal((g, nq, m)).astype(np.float32)
+        v[:, 0, :] = 0.25                       # all equal
+        if nq > 2:
+            v[:, 2, m // 2:] = -np.inf          # half the slots empty
+        got = T._native.dense_floor(dev(v), k).cpu().numpy()
+        for i in range(nq):
+            flat = np.sort(v[:, i, :].ravel())[::-1]
+            exp = flat[k - 1] if flat.size >= k and np.isfinite(flat[k - 1]) else -np.inf
+            assert got[i] == exp, (g, m, k, i)
+    with pytest.raises(T._native.NativeError):
+        T._native.dense_floor(dev(np.zeros((65, 2, 128), dtype=np.float32)), 10)
+
+
 def _sharded_worker(rank, world, port, n, d, out_dir):
     import os
     import sys
@@ -1235,7 +1359,16 @@ def _sharded_worker(rank, world, port, n, d, out_dir):
     qt = synth.lexical_queries(24, dfq, 4)
     seeds = synth.graph_queries(24, n, 3)
     sh = ShardedIndex(idx)
+    assert sh._floor_exchange() is not None     # the dense channel is split around the floor exchange
     res = sh.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    # ... which changes what a shard rescored, not a bit of any result
+    res0 = ShardedIndex(idx, floor=False).retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10)
+    assert torch.equal(res0.ids, res.ids) and torch.equal(res0.scores, res.scores)
+    for name in ("semantic", "lexical", "graph"):
+        assert torch.equal(res0.channels[name][0], res.channels[name][0]), name
+        assert torch.equal(res0.channels[name][1], res.channels[name][1]), name
+    _, _, c_floor, _ = idx.dense_search(dev(q), 100, sync=False, floor_exchange=sh._floor_exchange())
+    np.save(os.path.join(out_dir, f"floor_cnt_{rank}.npy"), c_floor.cpu().numpy())
     rr = sh.retrieve_batch(dev(q), dev(qt), dev(seeds), top_k=10, qtok=dev(synth.query_tokens(24, 32, 64)),
                            rerank_top_k=100)
     if rank == 0:
@@ -1270,6 +1403,9 @@ def test_two_rank_doc_sharded_pipeline_on_one_gpu(T, tmp_path):
     _, Id, _ = CO.dense_topk_exact(x, q, 100)
     _, Il = O.bm25_topk(csr.rowptr, csr.post_doc, csr.post_tf, csr.doclen, idf, avgdl, qt, n, 50)
     _, Ig = O.graph_topk(g.ent_rowptr, g.ent_col, g.men_rowptr, g.men_chunk, g.men_conf, seeds, 2, n, 50)
+    # the floor path: the two shards together rescored little more than the 100 rows of the answer
+    fc = np.load(tmp_path / "floor_cnt_0.npy").astype(int) + np.load(tmp_path / "floor_cnt_1.npy")
+    assert np.all(fc >= 100) and fc.mean() < 140, fc
     rr_ids, rr_sc = np.load(tmp_path / "rr_ids.npy"), np.load(tmp_path / "rr_sc.npy")
     dtok, qtok = synth.doc_tokens(0, n, 32, 64), synth.query_tokens(24, 32, 64)
     for i in range(24):

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in thr_hip.h but not exported"
     assert sorted(T._native.EXPORTED_SYMBOLS) == names
-    assert lib.thr_abi_version() == T._native.ABI_VERSION == 8
+    assert lib.thr_abi_version() == T._native.ABI_VERSION == 9
     assert lib.thr_error_string(-3) == b"workspace too small"
 
 

@@ -24,7 +24,7 @@ THR_BM25_MAX_TERMS = 32
 THR_GRAPH_MAX_SEEDS = 16
 THR_RRF_MAX_PER_CHANNEL = 128
 THR_TOPK_MAX = 128
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 
@@ -57,6 +57,11 @@ _SIGNATURES = {
     "thr_dense_f16_max_queries": (_i32, [_i32, _i32]),
     "thr_dense_topk_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
                                   _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "thr_dense_shortlist_f16": (_i32, [_vp, _vp, _dbl, _vp, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp,
+                                       _vp, _sz, _vp]),
+    "thr_dense_floor": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "thr_dense_finish_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
+                                    _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_lexical_build_workspace_bytes": (_sz, [_i64, _i64]),
@@ -343,6 +348,73 @@ def dense_topk_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k
                                      flg.data_ptr(), pw,
                                      workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_topk_f16")
+    return S, I, cnt, flg
+
+
+def dense_shortlist_f16(docs, docs16, doc_rel_err: float, inv_norm, queries, kprime: int, m: int,
+                        workspace: torch.Tensor, doc_coll=None, query_coll=None) -> torch.Tensor:
+    """First half of the search split around the shards' exchange (thr_hip.h e1): the filter scan
+    (candidate lists left in ``workspace``) and per query the ``m`` largest scan scores as lower
+    bounds of ||q|| x cosine -> float32 [nq, m], -inf padded."""
+    pd = _dev(docs, torch.float32, "docs", 2)
+    ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
+    n, d = docs.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    nq = queries.shape[0]
+    if queries.shape[1] != d or inv_norm.shape[0] != n:
+        raise NativeError("shortlist: shape mismatch")
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    need = dense_f16_workspace_bytes(n, d, nq, kprime)
+    if workspace.numel() * workspace.element_size() < need:
+        raise NativeError("shortlist: workspace smaller than thr_dense_f16_workspace_bytes")
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
+    lb = torch.empty((nq, m), dtype=torch.float32, device=docs.device)
+    _check(load().thr_dense_shortlist_f16(pd, ph, float(doc_rel_err), pi, n, d, pq, nq, kprime, pdc, pqc,
+                                          m, lb.data_ptr(), pw,
+                                          workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_shortlist_f16")
+    return lb
+
+
+def dense_floor(top_lb: torch.Tensor, k: int) -> torch.Tensor:
+    """[n_shards, nq, m] gathered lower bounds -> float32 [nq]: the k-th largest per query, a lower
+    bound of ||q|| x the k-th best cosine over all the shards (-inf: no floor)."""
+    p = _dev(top_lb, torch.float32, "top_lb", 3)
+    g, nq, m = top_lb.shape
+    out = torch.empty(nq, dtype=torch.float32, device=top_lb.device)
+    _check(load().thr_dense_floor(p, g, nq, m, k, out.data_ptr(), _stream()), "thr_dense_floor")
+    return out
+
+
+def dense_finish_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k: int, kprime: int,
+                     gfloor: Optional[torch.Tensor], id_base: int, workspace: torch.Tensor,
+                     doc_coll=None, query_coll=None):
+    """Second half: band, float64 rescoring, order and certificate on the candidate lists the
+    matching dense_shortlist_f16 call left in ``workspace`` (same arguments), with the shards'
+    common floor."""
+    pd = _dev(docs, torch.float32, "docs", 2)
+    ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
+    n, d = docs.shape
+    pq = _dev(queries, torch.float32, "queries", 2)
+    nq = queries.shape[0]
+    pn = _dev(dnorm, torch.float64, "dnorm", 1)
+    pi = _dev(inv_norm, torch.float32, "inv_norm", 1)
+    if queries.shape[1] != d or dnorm.shape[0] != n or inv_norm.shape[0] != n:
+        raise NativeError("finish: shape mismatch")
+    pg = None
+    if gfloor is not None:
+        pg = _dev(gfloor, torch.float32, "gfloor", 1)
+        if gfloor.shape[0] != nq:
+            raise NativeError("gfloor: one value per query")
+    pw = _dev(workspace, workspace.dtype, "workspace")
+    S, I, cnt, flg = _alloc_out(nq, k, docs.device)
+    pdc, pqc = _coll(doc_coll, query_coll, n, nq)
+    _check(load().thr_dense_finish_f16(pd, ph, float(doc_rel_err), pn, pi, n, d, id_base, pq, nq, k,
+                                       kprime, pdc, pqc, pg, S.data_ptr(), I.data_ptr(),
+                                       cnt.data_ptr(), flg.data_ptr(), pw,
+                                       workspace.numel() * workspace.element_size(), _stream()),
+           "thr_dense_finish_f16")
     return S, I, cnt, flg
 
 

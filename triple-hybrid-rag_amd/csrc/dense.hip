@@ -446,13 +446,23 @@ static size_t band_lds_bytes(int dim) { return sizeof(float) * dim + sizeof(int)
 // trips (segment counts -> candidates -> histogram -> band), which only occupancy hides.
 // Writes sel_rows[q][0..ns), sel_meta[q] = {ns, floor (float bits), overflow}.
 constexpr int CAPB = SEL_BIG_BAND;   // rows the band may hold
+//
+// Document shards (thr_dense_shortlist_f16 / thr_dense_floor / thr_dense_finish_f16): TOPM = true is
+// the pass BEFORE the exchange -- the query's top_m largest scan scores, each lowered by the scan's
+// error bound to a lower bound of ||q|| x (true cosine) of its row, written to top_lb[q][0..top_m)
+// (-inf padded) and nothing else.  The k-th largest of the shards' values together, gfloor[q], is
+// then a lower bound of ||q|| x (the GLOBAL k-th best cosine): in the pass after the exchange a
+// row whose scan score is below gfloor - 1.5 eps ||q|| cannot be one of the global k best and is
+// not rescored -- a shard of G rescores about k / G rows instead of k.
+template <bool TOPM>
 __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
     int dim, const float* __restrict__ queries, const float* __restrict__ tau,
     const int* __restrict__ cand_cnt, const Cand* __restrict__ cand,
     const int* __restrict__ tile_cnt, int tile_cap, int qtile, int k, int kprime, double eps32,
     double doc_relerr, const float* __restrict__ qerr, int nseg, int seg_cap,
     const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
-    int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_meta) {
+    int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_meta,
+    const float* __restrict__ gfloor, float* __restrict__ top_lb, int top_m) {
     extern __shared__ float4 lds_sel[];  // [dim/4] query | hist
     __shared__ int aux[8];
     __shared__ int bc[4];
@@ -588,6 +598,42 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
     }
     const double qn_hi = sqrt(wsum[0] + wsum[1] + wsum[2] + wsum[3]) * (1.0 + 1e-6);
 
+    if (TOPM) {
+        // the top_m largest scan scores, as lower bounds of ||q|| x cosine (the float conversion
+        // may round up: one step down)
+        float* o = top_lb + (int64_t)q * top_m;
+        const double drop = eps * qn_hi;
+        auto lowered = [&](float sc) { return nextafterf((float)((double)sc - drop), -INFINITY); };
+        for (int i = threadIdx.x; i < top_m; i += SEL_THREADS) o[i] = -INFINITY;
+        __syncthreads();
+        if (n > top_m) {
+            const uint32_t tkey = block_radix_select_local(
+                [&](int u) { return fkey(load_cand(u).score); }, my_n, top_m, hist, bc);
+            for (int u = 0; u < my_n; ++u) {
+                const Cand e = load_cand(u);
+                if (fkey(e.score) > tkey) o[atomicAdd(&n_sel, 1)] = lowered(e.score);
+            }
+            __syncthreads();
+            for (int u = 0; u < my_n; ++u) {
+                const Cand e = load_cand(u);
+                if (fkey(e.score) == tkey) {
+                    const int p = atomicAdd(&n_sel, 1);
+                    if (p < top_m) o[p] = lowered(e.score);
+                }
+            }
+        } else {
+            for (int u = 0; u < my_n; ++u) {
+                const Cand e = load_cand(u);
+                if (e.score > -INFINITY) o[atomicAdd(&n_sel, 1)] = lowered(e.score);
+            }
+        }
+        return;
+    }
+
+    // the shards' common floor: rows below gband_lo cannot be among the global k best
+    const float gF = gfloor ? gfloor[q] : -INFINITY;
+    float band_lo = -INFINITY;
+    if (gF > -INFINITY) band_lo = nextafterf((float)((double)gF - 1.5 * eps * qn_hi), -INFINITY);
     float floor32 = tau[q];
     bool band_done = false;
     if (n > k) {
@@ -652,38 +698,39 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
         __syncthreads();
         a_k = fminf(fminf(fred[2][0], fred[2][1]), fminf(fred[2][2], fred[2][3]));
         const float band = (float)((double)a_k - 2.5 * eps * qn_hi);
-        const float band_lo = nextafterf(band, -INFINITY);  // the float conversion may have rounded up
-        if (band_lo > -INFINITY) {
-            // count and collect in one sweep; past CAPB rows only the count matters
+        // (the float conversion may have rounded up); either bound rules a row out: the higher one
+        band_lo = fmaxf(band_lo, nextafterf(band, -INFINITY));
+    }
+    if (band_lo > -INFINITY) {
+        // count and collect in one sweep; past CAPB rows only the count matters
 #pragma unroll
-            for (int u = 0; u < SEL_REG; ++u) {   // (one LDS atomic per wave and register slot)
-                const bool in = u < my_n && mine[u].score >= band_lo;
-                const unsigned long long m = __ballot(in);
-                if (m) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&n_sel, __popcll(m));
-                    base = __shfl(base, 0, WAVE);
-                    const int p = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (in && p < CAPB) s_id[p] = mine[u].doc;
-                }
+        for (int u = 0; u < SEL_REG; ++u) {   // (one LDS atomic per wave and register slot)
+            const bool in = u < my_n && mine[u].score >= band_lo;
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&n_sel, __popcll(m));
+                base = __shfl(base, 0, WAVE);
+                const int p = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && p < CAPB) s_id[p] = mine[u].doc;
             }
-            for (int u = SEL_REG; u < my_n; ++u) {
-                const Cand e = load_cand(u);
-                if (e.score >= band_lo) {   // (band_lo > -inf: filtered candidates never pass)
-                    const int p = atomicAdd(&n_sel, 1);
-                    if (p < CAPB) s_id[p] = e.doc;
-                }
+        }
+        for (int u = SEL_REG; u < my_n; ++u) {
+            const Cand e = load_cand(u);
+            if (e.score >= band_lo) {   // (band_lo > -inf: filtered candidates never pass)
+                const int p = atomicAdd(&n_sel, 1);
+                if (p < CAPB) s_id[p] = e.doc;
             }
+        }
+        __syncthreads();
+        if (n_sel <= CAPB) {
+            // rows outside the band: uncollected ones are below tau, collected ones below band_lo
+            floor32 = fmaxf(floor32, band_lo);
+            band_done = true;
+        } else {
             __syncthreads();
-            if (n_sel <= CAPB) {
-                // rows outside the band: uncollected ones are below tau, collected ones below band_lo
-                floor32 = fmaxf(floor32, band_lo);
-                band_done = true;
-            } else {
-                __syncthreads();
-                if (threadIdx.x == 0) n_sel = 0;
-                __syncthreads();
-            }
+            if (threadIdx.x == 0) n_sel = 0;
+            __syncthreads();
         }
     }
     if (!band_done) {
@@ -727,6 +774,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
         sel_meta[4 * q + 0] = ns;
         sel_meta[4 * q + 1] = (int32_t)__float_as_uint(floor32);
         sel_meta[4 * q + 2] = overflow ? 1 : 0;
+        sel_meta[4 * q + 3] = (int32_t)__float_as_uint(gF);
     }
 }
 
@@ -873,12 +921,16 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
             cert = false;
         } else if (floor32 == -INFINITY) {
             cert = true;  // every row with an embedding was rescored
-        } else if (valid < k) {
-            cert = false;
         } else {
             // rows outside the shortlist have scan score <= floor32, hence true
-            // cosine <= floor32/||q|| + eps; the k-th best must clear that strictly.
-            cert = s_qn > 0.0 && (o_s[k - 1] - (double)floor32 / s_qn) > eps;
+            // cosine <= floor32/||q|| + eps; the k-th best must clear that strictly -- this
+            // shard's own k-th best, or the k-th best of all the shards, of which gF / ||q|| is a
+            // lower bound (then the list may be shorter than k: the rest is on other shards).
+            const float gF = __uint_as_float((uint32_t)sel_meta[4 * q + 3]);
+            const bool own = valid >= k && s_qn > 0.0 && (o_s[k - 1] - (double)floor32 / s_qn) > eps;
+            const bool all = gF > -INFINITY && s_qn > 0.0 &&
+                             ((double)gF / s_qn - (double)floor32 / s_qn) > eps;
+            cert = own || all;
         }
         out_flags[q] = flag | (cert ? THR_FLAG_CERTIFIED : 0u);
         out_counts[q] = valid;
@@ -1197,6 +1249,31 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     return p;
 }
 
+// The shards' common floor: the k-th largest of the n_shards * m lower bounds of a query
+// (select_band<true> of every shard, gathered shard-major), -inf when fewer than k are finite.
+// One workgroup per query; rank counting in LDS (n_shards * m is a few hundred values).
+__global__ __launch_bounds__(256) void dense_floor_kernel(const float* __restrict__ lb, int n_shards,
+                                                          int n_queries, int m, int k,
+                                                          float* __restrict__ gfloor) {
+    extern __shared__ float fl_v[];
+    const int q = blockIdx.x, n = n_shards * m;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        fl_v[i] = lb[((int64_t)(i / m) * n_queries + q) * m + i % m];
+    if (threadIdx.x == 0) gfloor[q] = -INFINITY;
+    __syncthreads();
+    if (n < k) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = fl_v[i];
+        if (!(v > -INFINITY)) continue;
+        int rank = 0;   // values ahead of v: larger ones, equal ones of a lower index
+        for (int j = 0; j < n; ++j) {
+            const float w = fl_v[j];
+            rank += (w > v || (w == v && j < i)) ? 1 : 0;
+        }
+        if (rank == k - 1) gfloor[q] = v;
+    }
+}
+
 static int g_num_cus = 0;
 static int num_cus() {
     if (!g_num_cus) {
@@ -1421,12 +1498,16 @@ extern "C" size_t thr_dense_workspace_bytes(int64_t n_docs, int dim, int n_queri
 
 // K1..K4 for every scan flavour.  p.kind == KIND_F32: float32 MFMA scan; KIND_F16: f16 MFMA scan
 // over docs16, or over the float32 rows rounded in flight when docs16 == nullptr.
+// phase: PIPE_ALL = one call; PIPE_SHORTLIST = K1..K3 + the top_m lower bounds (the candidate
+// lists stay in the workspace); PIPE_FINISH = K4 on those lists with the shards' common floor.
+enum { PIPE_ALL = 0, PIPE_SHORTLIST = 1, PIPE_FINISH = 2 };
 static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16* docs16,
                           double doc_relerr, const double* dnorm, const float* inv_norm,
                           int64_t n_docs, int dim, int64_t id_base, const float* queries,
                           int n_queries, int k, int kprime, double* out_scores, int64_t* out_ids,
                           int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st,
-                          const int32_t* doc_coll, const int32_t* query_coll) {
+                          const int32_t* doc_coll, const int32_t* query_coll, int phase = PIPE_ALL,
+                          const float* gfloor = nullptr, float* top_lb = nullptr, int top_m = 0) {
     float* tau = (float*)(ws + p.off_tau);
     const bool h = p.kind == KIND_F16;
     float* qerr = h ? (float*)(ws + p.off_qerr) : nullptr;
@@ -1459,9 +1540,20 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                                                   p.ntiles, units, stride, tau, tcnt, tlist,
                                                   p.tile_cap, nullptr, 0, st, doc_coll, query_coll);
     };
+    int rc;
+    const double u = 5.9604644775390625e-08;
+    const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
+    int32_t* sel_rows = (int32_t*)(ws + p.off_selrows);
+    int32_t* sel_meta = (int32_t*)(ws + p.off_selmeta);
+    if (phase == PIPE_FINISH) {
+        // (the candidate area's layout as the filter scan of the shortlist call left it)
+        if (p.qreg && (rc = launch_scan_f16q<MODE_FILTER, true>(dim, docs16, qfrag, p.ntiles, p.groups, 1,
+                                                                 nullptr, nullptr, nullptr, nullptr, 0, st,
+                                                                 &nseg)))
+            return rc;
+    } else {
     hipError_t e = hipMemsetAsync(cnt, 0, p.off_cand - p.off_cnt, st);  // cnt + tcnt
     if (e != hipSuccess) return (int)e;
-    int rc;
     // (the qreg scan's query image comes with the query-side error term; kth_select then skips it)
     if (p.qreg && (rc = launch_pack_queries(dim, queries, n_queries, p.qpad, qfrag, qerr, st))) return rc;
     float* qerr_k2 = p.qreg ? nullptr : qerr;
@@ -1482,13 +1574,18 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                            tlist, p.tile_cap, p.qtile, p.row_bits, cnt, cand);
         if ((rc = launch_status())) return rc;
     }
-    const double u = 5.9604644775390625e-08;
-    const double eps32 = h ? ((double)dim + 16.0) * u : scan_eps(dim);
-    int32_t* sel_rows = (int32_t*)(ws + p.off_selrows);
-    int32_t* sel_meta = (int32_t*)(ws + p.off_selmeta);
-    hipLaunchKernelGGL(select_band, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st, dim,
-                       queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32, doc_relerr,
-                       qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll, sel_rows, sel_meta);
+    }
+    if (phase == PIPE_SHORTLIST) {
+        hipLaunchKernelGGL(select_band<true>, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st,
+                           dim, queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32,
+                           doc_relerr, qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll,
+                           sel_rows, sel_meta, (const float*)nullptr, top_lb, top_m);
+        return launch_status();
+    }
+    hipLaunchKernelGGL(select_band<false>, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st,
+                       dim, queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32,
+                       doc_relerr, qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll,
+                       sel_rows, sel_meta, gfloor, (float*)nullptr, 0);
     if ((rc = launch_status())) return rc;
     hipLaunchKernelGGL(rescore_rank<THR_DENSE_MAX_K>, dim3(n_queries), dim3(RR_THREADS),
                        rescore_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, k, eps32,
@@ -1603,6 +1700,69 @@ extern "C" int thr_dense_topk_f16(const float* docs, const uint16_t* docs16, dou
                           inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
                           out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream,
                           doc_coll, query_coll);
+}
+
+static int f16_args_ok(const float* docs, const uint16_t* docs16, double doc_rel_err, int64_t n_docs,
+                       int dim, int n_queries, const int32_t* doc_coll, const int32_t* query_coll) {
+    (void)docs;
+    THR_RETURN_IF((query_coll != nullptr) != (doc_coll != nullptr), THR_ERR_INVALID);
+    THR_RETURN_IF(!(doc_rel_err >= 0.0) || !(doc_rel_err < 1.0), THR_ERR_INVALID);
+    THR_RETURN_IF(dim != 512 && dim != 768 && dim != 1024, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(n_docs >= (int64_t)1 << ROW_BITS_F16, THR_ERR_UNSUPPORTED);
+    THR_RETURN_IF(docs16 != nullptr && n_queries > qreg_max_queries(dim), THR_ERR_UNSUPPORTED);
+    return THR_OK;
+}
+
+extern "C" int thr_dense_shortlist_f16(const float* docs, const uint16_t* docs16, double doc_rel_err,
+                                       const float* inv_norm, int64_t n_docs, int dim,
+                                       const float* queries, int n_queries, int kprime,
+                                       const int32_t* doc_coll, const int32_t* query_coll, int m,
+                                       float* top_lb, void* workspace, size_t workspace_bytes,
+                                       thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!docs || !inv_norm || !queries || !top_lb || !workspace, THR_ERR_INVALID);
+    THR_RETURN_IF(n_docs <= 0 || n_queries <= 0 || kprime <= 0 || kprime > THR_DENSE_MAX_K || m <= 0 ||
+                      m > THR_DENSE_MAX_K,
+                  THR_ERR_INVALID);
+    int rc = f16_args_ok(docs, docs16, doc_rel_err, n_docs, dim, n_queries, doc_coll, query_coll);
+    if (rc) return rc;
+    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, docs16 != nullptr);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, nullptr,
+                          inv_norm, n_docs, dim, 0, queries, n_queries, 0, kprime, nullptr, nullptr,
+                          nullptr, nullptr, (char*)workspace, (hipStream_t)stream, doc_coll, query_coll,
+                          PIPE_SHORTLIST, nullptr, top_lb, m);
+}
+
+extern "C" int thr_dense_floor(const float* top_lb, int n_shards, int n_queries, int m, int k,
+                               float* gfloor, thr_stream_t stream) {
+    clear_status();
+    THR_RETURN_IF(!top_lb || !gfloor || n_shards <= 0 || n_queries <= 0 || m <= 0 || k <= 0, THR_ERR_INVALID);
+    THR_RETURN_IF((int64_t)n_shards * m > 8192, THR_ERR_CAPACITY);
+    hipLaunchKernelGGL(dense_floor_kernel, dim3(n_queries), dim3(256), sizeof(float) * n_shards * m,
+                       (hipStream_t)stream, top_lb, n_shards, n_queries, m, k, gfloor);
+    return launch_status();
+}
+
+extern "C" int thr_dense_finish_f16(const float* docs, const uint16_t* docs16, double doc_rel_err,
+                                    const double* dnorm, const float* inv_norm, int64_t n_docs,
+                                    int dim, int64_t id_base, const float* queries, int n_queries,
+                                    int k, int kprime, const int32_t* doc_coll,
+                                    const int32_t* query_coll, const float* gfloor,
+                                    double* out_scores, int64_t* out_ids, int32_t* out_counts,
+                                    uint32_t* out_flags, void* workspace, size_t workspace_bytes,
+                                    thr_stream_t stream) {
+    clear_status();
+    int rc = dense_args_ok(docs, dnorm, inv_norm, queries, out_scores, out_ids, out_counts,
+                           out_flags, workspace, n_docs, n_queries, k, kprime);
+    if (rc) return rc;
+    if ((rc = f16_args_ok(docs, docs16, doc_rel_err, n_docs, dim, n_queries, doc_coll, query_coll))) return rc;
+    const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, docs16 != nullptr);
+    THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
+    return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
+                          inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
+                          out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream,
+                          doc_coll, query_coll, PIPE_FINISH, gfloor);
 }
 
 extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,

@@ -137,10 +137,18 @@ def gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
 class ShardedIndex:
     """A GpuIndex holding this rank's document shard + the cross-rank merge."""
 
-    def __init__(self, local: GpuIndex, group=None):
+    def __init__(self, local: GpuIndex, group=None, floor: bool = True):
         self.local = local
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # the dense channel split around one more (small) exchange, so that a shard rescores its
+        # share of the global top-k instead of a top-k of its own (GpuIndex.dense_search)
+        self.floor = floor
+
+    def _floor_exchange(self):
+        if self.world == 1 or not self.floor or self.local.shortlist not in ("f16", "f16-inline"):
+            return None
+        return (lambda lb: gather_rows(lb, self.group)), self.world
 
     def _merge(self, S, I, k):
         if self.world == 1:
@@ -165,7 +173,8 @@ class ShardedIndex:
         # the lexical and graph kernels run on a side stream beside the dense channel; the
         # exchanges stay on the main stream, after the join
         lex, gra, join = L.side_channels(query_terms, lexical_top_k, query_seeds, graph_top_k, hops)
-        Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False)
+        Ss, Is, _, nres = L.dense_search(queries, semantic_top_k, sync=False,
+                                         floor_exchange=self._floor_exchange())
         join()
         # ONE exchange for all the channels of the batch, then a merge per channel
         names, locals_, ks = ["semantic"], [(Ss, Is)], [semantic_top_k]

@@ -34,6 +34,14 @@ from . import _native as N
 log = logging.getLogger(__name__)
 
 
+def floor_width(k: int, n_shards: int) -> int:
+    """Lower bounds a shard sends per query for the common floor (thr_dense_floor): twice its fair
+    share of the k best, at least 16 -- the k-th largest of the n_shards * m values is then close
+    to the true k-th score unless one shard holds most of the k best."""
+    m = max(16, 2 * -(-k // max(1, n_shards)))
+    return max(1, min(m, N.THR_DENSE_MAX_K, 8192 // max(1, n_shards)))
+
+
 @dataclass
 class BatchResult:
     ids: torch.Tensor            # int64 [nq, top_k] fused (or reranked) global doc ids, -1 pad
@@ -300,13 +308,20 @@ class GpuIndex:
         return 1 << 30
 
     def dense_search(self, queries: torch.Tensor, k: int, kprime: Optional[int] = None,
-                     rescue: bool = True, sync: bool = True, collections=None):
+                     rescue: bool = True, sync: bool = True, collections=None, floor_exchange=None):
         """Exact cosine top-k -> (scores f64, ids i64, counts i32, n_rescued).  Queries the
         error-bound certificate cannot prove exact (massive ties / duplicates) are redone on the
         exhaustive float64 path, on the device (thr_dense_rescue: no host read-back).
         n_rescued is an int, or with sync=False the device int32[1] it would be read from.
         collections: int32 [nq] collection id per query (-1 = unfiltered), applied before the
-        ranking (set_collections)."""
+        ranking (set_collections).
+        floor_exchange: (callable, n_shards) of a DOCUMENT-SHARDED index -- the callable maps this
+        shard's float32 [nq, m] lower bounds to all the shards' [n_shards, nq, m] (an all-gather).
+        The search is then split around that one exchange (thr_dense_shortlist_f16 / thr_dense_floor
+        / thr_dense_finish_f16): rows that cannot be among the k best of ALL shards are not
+        rescored, the returned list may hold fewer than k rows and is this shard's part of the
+        global top-k (merge the shards' lists with thr_merge_topk).  Every shard must make the same
+        sequence of calls.  Used by the f16 scans only."""
         queries = self._t(queries, torch.float32)
         nq = queries.shape[0]
         if self.shortlist == "f16":
@@ -320,7 +335,8 @@ class GpuIndex:
                 for lo in range(0, nq, step):
                     hi = min(nq, lo + step)
                     s_, i_, c_, r_ = self.dense_search(queries[lo:hi], k, kprime, rescue, sync,
-                                                       None if coll is None else coll[lo:hi])
+                                                       None if coll is None else coll[lo:hi],
+                                                       floor_exchange)
                     S[lo:hi], I[lo:hi], cnt[lo:hi] = s_, i_, c_
                     n_rescued = n_rescued + r_
                 return S, I, cnt, n_rescued
@@ -334,9 +350,19 @@ class GpuIndex:
             kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 92)))
             ws = self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim,
                                                              queries.shape[0], kp))
-            S, I, cnt, flg = N.dense_topk_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
-                                              self.inv_norm, queries, k, kp, self.doc_base, ws,
-                                              doc_coll=dc, query_coll=qc)
+            if floor_exchange is not None:
+                exchange, n_shards = floor_exchange
+                lb = N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm,
+                                           queries, kp, floor_width(k, n_shards), ws,
+                                           doc_coll=dc, query_coll=qc)
+                gfloor = N.dense_floor(exchange(lb), k)
+                S, I, cnt, flg = N.dense_finish_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
+                                                    self.inv_norm, queries, k, kp, gfloor, self.doc_base,
+                                                    ws, doc_coll=dc, query_coll=qc)
+            else:
+                S, I, cnt, flg = N.dense_topk_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
+                                                  self.inv_norm, queries, k, kp, self.doc_base, ws,
+                                                  doc_coll=dc, query_coll=qc)
         else:
             kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 28)))
             ws = self._workspace(N.dense_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
@@ -352,6 +378,43 @@ class GpuIndex:
             if sync:
                 n_rescued = int(n_rescued)
         return S, I, cnt, n_rescued
+
+    # The two halves of dense_search(floor_exchange=...) on their own, for a caller that holds
+    # several shards in ONE process (tests, bench.py's shard proxy): shortlist on every shard,
+    # stack the results, thr_dense_floor, finish on every shard.
+    def _f16_call(self, queries, k, kprime, collections):
+        if self.shortlist not in ("f16", "f16-inline"):
+            raise N.NativeError("the shard floor is built for the f16 scans")
+        queries = self._t(queries, torch.float32)
+        if queries.shape[0] > self.max_batch():
+            raise N.NativeError("dense_shortlist/finish: one scan batch at a time (max_batch())")
+        kp = min(N.THR_DENSE_MAX_K, max(k, kprime or (k + 92)))
+        ws = self._workspace(N.dense_f16_workspace_bytes(self.n_docs, self.dim, queries.shape[0], kp))
+        dc, qc = self._qcoll(collections, queries.shape[0])
+        return queries, kp, ws, dc, qc
+
+    def dense_shortlist(self, queries: torch.Tensor, k: int, n_shards: int, kprime: Optional[int] = None,
+                        collections=None) -> torch.Tensor:
+        queries, kp, ws, dc, qc = self._f16_call(queries, k, kprime, collections)
+        return N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm, queries, kp,
+                                     floor_width(k, n_shards), ws, doc_coll=dc, query_coll=qc)
+
+    def dense_finish(self, queries: torch.Tensor, k: int, gfloor: Optional[torch.Tensor],
+                     kprime: Optional[int] = None, rescue: bool = True, collections=None):
+        """-> (scores, ids, counts, flags BEFORE the rescue, n_rescued device int32[1] or 0)."""
+        queries, kp, ws, dc, qc = self._f16_call(queries, k, kprime, collections)
+        S, I, cnt, flg = N.dense_finish_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
+                                            self.inv_norm, queries, k, kp, gfloor, self.doc_base, ws,
+                                            doc_coll=dc, query_coll=qc)
+        flags0 = flg.clone()
+        n_rescued = 0
+        if rescue:
+            need = N.dense_rescue_workspace_bytes(queries.shape[0], k)
+            if self._ws_rescue is None or self._ws_rescue.numel() < need:
+                self._ws_rescue = torch.empty(need, dtype=torch.uint8, device=self.device)
+            n_rescued = N.dense_rescue(self.docs, self.dnorm, queries, S, I, cnt, flg, self.doc_base,
+                                       self._ws_rescue, doc_coll=dc, query_coll=qc)
+        return S, I, cnt, flags0, n_rescued
 
     def scan_probe(self, queries: torch.Tensor) -> None:
         """Launch ONLY the streaming scan kernel of the last dense_search (same workspace, so the
