@@ -77,6 +77,10 @@ def parse():
                          "headline corpus is 2 shards x N/2 replicas and the 10M-doc configs are N shards; "
                          "--doc-shards N forces the pure document-sharded layout")
     ap.add_argument("--min-shard-docs", type=int, default=500_000)
+    ap.add_argument("--shard-proxy", type=int, default=0, metavar="G",
+                    help="N = 1 only: also hold the --docs corpus as G document shards in THIS process and "
+                         "time one shard's share of a dense step (everything but the collectives) with and "
+                         "without the shard floor exchange -> config.shard_floor_proxy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=2048)
     ap.add_argument("--probe-reps", type=int, default=5)
@@ -345,13 +349,80 @@ def main():
             Sg_, Ig_, _ = B.index.graph_search(B.sd, 50, 2)
             pairs.append((Sg_, Ig_))
         ex_ms = event_ms(lambda: gather_topk_many(pairs, B.group), 5, torch)
+        fx, fx_ms = B.sharded._floor_exchange(), 0.0
+        if fx is not None:   # the dense channel's floor exchange: nq x m float32 per rank
+            from triple_hybrid_rag_amd.index import floor_width
+            lb_ = torch.zeros((B.qd.shape[0], floor_width(100, fx[1])), dtype=torch.float32, device=B.qd.device)
+            fx_ms = event_ms(lambda: fx[0](lb_), 5, torch)
         step_ms = 1e3 * elapsed / args.steps
         return {"step_ms": round(step_ms, 3), "scan_ms": roof["launch_ms"], "exchange_ms": round(ex_ms, 3),
-                "fixed_ms": round(step_ms - roof["launch_ms"] - ex_ms, 3),
+                "floor_exchange_ms": round(fx_ms, 3) if fx is not None else None,
+                "fixed_ms": round(step_ms - roof["launch_ms"] - ex_ms - fx_ms, 3),
                 "exchange_bytes_per_rank": int(sum(2 * 8 * s_.numel() for s_, _ in pairs)),
                 "shard_docs": B.n_local,
                 "note": "rank 0; fixed = embed post-processing, threshold sample + select, shortlist, "
                         "float64 rescoring, merge, fusion"}
+
+    def shard_proxy(G):
+        """One rank's GPU work of a DOCUMENT-SHARDED dense step, measured on one GPU: the --docs
+        corpus as G shards resident in this process, every shard's kernels launched back to back
+        (each fills the chip, so the total / G is a shard's share), the all-gathers replaced by the
+        stacking copies that produce the same tensors.  Classic: every shard ranks a top-100 of its
+        own.  Floor: thr_dense_shortlist_f16 -> (exchange) -> thr_dense_floor -> thr_dense_finish_f16."""
+        from triple_hybrid_rag_amd.index import floor_width
+        N_ = T._native
+        shards = []
+        for s_ in range(G):
+            lo_, hi_ = shard_range(args.docs, s_, G)
+            ix = T.GpuIndex(doc_base=lo_).set_dense(synth.dense_rows(lo_, hi_ - lo_, args.dim),
+                                                    shortlist=args.shortlist)
+            ix.reserve(nq, 100)
+            shards.append(ix)
+        if shards[0].shortlist not in ("f16", "f16-inline"):
+            return None
+        last = {}
+
+        def tail(outs):
+            S_ = torch.stack([o[0] for o in outs])
+            I_ = torch.stack([o[1] for o in outs])
+            for _ in shards:   # every rank merges the gathered lists and fuses
+                _, Im, _ = N_.merge_topk(S_, I_, 100)
+                ids_, _, _, _ = N_.rrf_fuse(None, Im, None, args.top_k, 0.7, 0.8, 1.0)
+            last["ids"], last["counts"] = ids_, torch.stack([o[2] for o in outs])
+
+        def classic():
+            tail([ix.dense_search(N_.embed_postproc(B.raw_dev, args.dim), 100, sync=False) for ix in shards])
+
+        def floor():
+            # a rank runs shortlist -> exchange -> finish back to back (its candidate lists still in
+            # cache): shard by shard here, the finish taking the gathered bounds of the PREVIOUS
+            # repetition -- the same values, the inputs do not change
+            if "lbs" not in last:
+                last["lbs"] = torch.stack([ix.dense_shortlist(B.qd, 100, G) for ix in shards])
+            outs, lbs = [], []
+            for ix in shards:
+                q_ = N_.embed_postproc(B.raw_dev, args.dim)
+                lbs.append(ix.dense_shortlist(q_, 100, G))
+                outs.append(ix.dense_finish(q_, 100, lb_all=last["lbs"]))
+            last["lbs"] = torch.stack(lbs)
+            tail(outs)
+
+        reps = max(3, args.steps // 4)
+        classic()
+        ms_c = event_ms(classic, reps, torch) / G
+        ids_c, rows_c = last["ids"].clone(), float(last["counts"].float().mean())
+        floor()
+        ms_f = event_ms(floor, reps, torch) / G
+        same = bool(torch.equal(ids_c, last["ids"]))
+        rows_f = float(last["counts"].float().mean())
+        m = floor_width(100, G)
+        return {"shards": G, "rows_per_shard": args.docs // G, "queries_per_step": nq,
+                "ms_per_shard_step_classic": round(ms_c, 3), "ms_per_shard_step_floor": round(ms_f, 3),
+                "rows_rescored_per_query_and_shard": {"classic": round(rows_c, 1), "floor": round(rows_f, 1)},
+                "fused_ids_identical": same, "floor_exchange_bytes_per_rank": 4 * nq * m,
+                "note": "one GPU runs the G shards' kernels back to back; total / G; the collectives (one "
+                        "all-gather of the result lists; for the floor one more of nq x m float32) are NOT "
+                        "in these figures -- they have never run on more than one GPU"}
 
     per_rank = strong = None
     if world > 1:
@@ -616,7 +687,9 @@ def main():
                                + ("" if head_cfg == "dense" else " + BM25 top-50" + (" + graph top-50" if head_cfg.startswith("triple") else ""))
                                + " -> weighted RRF -> fused top-10" + (" of the MaxSim-reranked top-100" if head_cfg == "triple_rerank" else ""),
                        "lexical_mix": args.lexical_mix if head_cfg != "dense" else None,
-                       "per_rank_ms": per_rank, "strong_doc_sharded": strong},
+                       "per_rank_ms": per_rank, "strong_doc_sharded": strong,
+                       "shard_floor_proxy": shard_proxy(args.shard_proxy)
+                       if world == 1 and args.shard_proxy > 1 else None},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if cfg_out:

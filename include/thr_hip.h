@@ -183,8 +183,11 @@ int thr_dense_topk_f16(const float *docs, const uint16_t *docs16 /* or NULL */, 
  *                            shard's own k-th score or against gfloor), and thr_dense_rescue
  *                            redoes the others exhaustively as before.  thr_merge_topk over the
  *                            shards' lists is then the exact top-k: no second exchange.
- * gfloor == NULL (or -inf entries) gives thr_dense_topk_f16's behaviour.  m <= THR_DENSE_MAX_K,
- * G * m <= 8192; choose m >= k / G, about 2 k / G for a floor close to the true k-th score. */
+ * The floor reaches thr_dense_finish_f16 either as gfloor (thr_dense_floor's output) or as the
+ * gathered bounds themselves (top_lb_all, n_shards, m; G * m <= 4096): the kernel that cuts the
+ * band then finds the k-th largest itself and thr_dense_floor is not launched at all.  Neither
+ * (or -inf entries) gives thr_dense_topk_f16's behaviour.  m <= THR_DENSE_MAX_K, G * m <= 8192
+ * for thr_dense_floor; choose m >= k / G, about 2 k / G for a floor close to the true k-th score. */
 int thr_dense_shortlist_f16(const float *docs, const uint16_t *docs16 /* or NULL */, double doc_rel_err,
                             const float *inv_norm, int64_t n_docs, int dim, const float *queries,
                             int n_queries, int kprime, const int32_t *doc_coll,
@@ -196,9 +199,11 @@ int thr_dense_finish_f16(const float *docs, const uint16_t *docs16 /* or NULL */
                          const double *dnorm, const float *inv_norm, int64_t n_docs, int dim,
                          int64_t id_base, const float *queries, int n_queries, int k, int kprime,
                          const int32_t *doc_coll, const int32_t *query_coll,
-                         const float *gfloor /* [nq] or NULL */, double *out_scores,
-                         int64_t *out_ids, int32_t *out_counts, uint32_t *out_flags,
-                         void *workspace, size_t workspace_bytes, thr_stream_t stream);
+                         const float *gfloor /* [nq] or NULL */,
+                         const float *top_lb_all /* [n_shards, nq, m] or NULL */, int n_shards, int m,
+                         double *out_scores, int64_t *out_ids, int32_t *out_counts,
+                         uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                         thr_stream_t stream);
 int thr_dense_scan_probe_f16(const float *docs, const uint16_t *docs16 /* or NULL */,
                              const float *inv_norm, int64_t n_docs, int dim, const float *queries,
                              int n_queries, void *workspace, size_t workspace_bytes,

@@ -1224,14 +1224,16 @@ def _floor_search(T, x, q, k, n_shards, shortlist="f16", coll=None, qc=None, use
         lbs = torch.stack([ix.dense_shortlist(qd, k, n_shards, collections=qcd) for ix in shards])
         assert lbs.shape == (n_shards, q.shape[0], T.index.floor_width(k, n_shards))
         gfloor = T._native.dense_floor(lbs, k)
-    else:
-        for ix in shards:   # (the finish reads the lists a shortlist call left)
-            ix.dense_shortlist(qd, k, n_shards, collections=qcd)
     outs = []
-    for ix in shards:
+    for si, ix in enumerate(shards):
         if not use_floor:
             ix.dense_shortlist(qd, k, n_shards, collections=qcd)
-        outs.append(ix.dense_finish(qd, k, gfloor, collections=qcd))
+        # the floor as thr_dense_floor's output on the even shards, as the gathered bounds
+        # themselves (the k-th largest found inside the band kernel) on the odd ones: the same thing
+        if use_floor and si % 2:
+            outs.append(ix.dense_finish(qd, k, lb_all=lbs, collections=qcd))
+        else:
+            outs.append(ix.dense_finish(qd, k, gfloor, collections=qcd))
     S = torch.stack([o[0] for o in outs])
     I = torch.stack([o[1] for o in outs])
     Sm, Im, cm = T._native.merge_topk(S, I, k)

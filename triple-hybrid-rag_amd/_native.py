@@ -61,7 +61,7 @@ _SIGNATURES = {
                                        _vp, _sz, _vp]),
     "thr_dense_floor": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "thr_dense_finish_f16": (_i32, [_vp, _vp, _dbl, _vp, _vp, _i64, _i32, _i64, _vp, _i32, _i32,
-                                    _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                    _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "thr_dense_scan_probe_f16": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "thr_dense_scan_stamps_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _sz, _vp, C.POINTER(_i32), _vp]),
     "thr_lexical_build_workspace_bytes": (_sz, [_i64, _i64]),
@@ -389,10 +389,11 @@ def dense_floor(top_lb: torch.Tensor, k: int) -> torch.Tensor:
 
 def dense_finish_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries, k: int, kprime: int,
                      gfloor: Optional[torch.Tensor], id_base: int, workspace: torch.Tensor,
-                     doc_coll=None, query_coll=None):
+                     doc_coll=None, query_coll=None, lb_all: Optional[torch.Tensor] = None):
     """Second half: band, float64 rescoring, order and certificate on the candidate lists the
     matching dense_shortlist_f16 call left in ``workspace`` (same arguments), with the shards'
-    common floor."""
+    common floor: ``gfloor`` [nq] (dense_floor's output), or ``lb_all`` [n_shards, nq, m] -- the
+    gathered bounds themselves, the k-th largest found inside the band kernel."""
     pd = _dev(docs, torch.float32, "docs", 2)
     ph = _dev(docs16, torch.float16, "docs16", 2) if docs16 is not None else None
     n, d = docs.shape
@@ -407,11 +408,19 @@ def dense_finish_f16(docs, docs16, doc_rel_err: float, dnorm, inv_norm, queries,
         pg = _dev(gfloor, torch.float32, "gfloor", 1)
         if gfloor.shape[0] != nq:
             raise NativeError("gfloor: one value per query")
+    pl, g, m = None, 0, 0
+    if lb_all is not None:
+        if gfloor is not None:
+            raise NativeError("finish: gfloor or lb_all, not both")
+        pl = _dev(lb_all, torch.float32, "lb_all", 3)
+        g, nq_l, m = lb_all.shape
+        if nq_l != nq:
+            raise NativeError("lb_all: [n_shards, nq, m]")
     pw = _dev(workspace, workspace.dtype, "workspace")
     S, I, cnt, flg = _alloc_out(nq, k, docs.device)
     pdc, pqc = _coll(doc_coll, query_coll, n, nq)
     _check(load().thr_dense_finish_f16(pd, ph, float(doc_rel_err), pn, pi, n, d, id_base, pq, nq, k,
-                                       kprime, pdc, pqc, pg, S.data_ptr(), I.data_ptr(),
+                                       kprime, pdc, pqc, pg, pl, g, m, S.data_ptr(), I.data_ptr(),
                                        cnt.data_ptr(), flg.data_ptr(), pw,
                                        workspace.numel() * workspace.element_size(), _stream()),
            "thr_dense_finish_f16")

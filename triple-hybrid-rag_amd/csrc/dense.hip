@@ -437,7 +437,6 @@ __device__ __forceinline__ double seq_dot_f64(const float* __restrict__ a, const
 constexpr int SEL_THREADS = 256;
 constexpr int RS_STRIDE = 9;       // float4 slots per staged row: 8 + 1 pad (conflict-free b128)
 constexpr int SEL_REG = 16;        // candidates per thread kept in registers (4096 per query; the scan aims at ~2900)
-constexpr int RS_DEPTH = 2;        // 32-dim chunks of a row in flight per wave (dim / 32 is a multiple)
 constexpr int SEL_BIG_BAND = 1024; // band capacity of the second-chance launch
 constexpr int SEL_FLAT = 8192;     // candidates of the per-lane segments addressed through a flat LDS index
 static size_t band_lds_bytes(int dim) { return sizeof(float) * dim + sizeof(int) * CS_BINS; }
@@ -462,7 +461,8 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
     double doc_relerr, const float* __restrict__ qerr, int nseg, int seg_cap,
     const int32_t* __restrict__ doc_coll, const int32_t* __restrict__ query_coll,
     int32_t* __restrict__ sel_rows, int32_t* __restrict__ sel_meta,
-    const float* __restrict__ gfloor, float* __restrict__ top_lb, int top_m) {
+    const float* __restrict__ gfloor, const float* __restrict__ lb_all, int n_shards, int lb_m,
+    float* __restrict__ top_lb, int top_m) {
     extern __shared__ float4 lds_sel[];  // [dim/4] query | hist
     __shared__ int aux[8];
     __shared__ int bc[4];
@@ -598,45 +598,49 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
     }
     const double qn_hi = sqrt(wsum[0] + wsum[1] + wsum[2] + wsum[3]) * (1.0 + 1e-6);
 
-    if (TOPM) {
-        // the top_m largest scan scores, as lower bounds of ||q|| x cosine (the float conversion
-        // may round up: one step down)
-        float* o = top_lb + (int64_t)q * top_m;
-        const double drop = eps * qn_hi;
-        auto lowered = [&](float sc) { return nextafterf((float)((double)sc - drop), -INFINITY); };
-        for (int i = threadIdx.x; i < top_m; i += SEL_THREADS) o[i] = -INFINITY;
-        __syncthreads();
-        if (n > top_m) {
-            const uint32_t tkey = block_radix_select_local(
-                [&](int u) { return fkey(load_cand(u).score); }, my_n, top_m, hist, bc);
-            for (int u = 0; u < my_n; ++u) {
-                const Cand e = load_cand(u);
-                if (fkey(e.score) > tkey) o[atomicAdd(&n_sel, 1)] = lowered(e.score);
+    // the shards' common floor: rows below it cannot be among the k best of all the shards.  Given
+    // as gfloor[q], or as the shards' gathered lower bounds lb_all [n_shards, nq, lb_m]: the k-th
+    // largest of this query's n_shards * lb_m values, found here by rank counting (<= 4096 values
+    // in the LDS words of the histogram, which is not in use yet).
+    float gF = -INFINITY;
+    if (!TOPM) {
+        if (gfloor) {
+            gF = gfloor[q];
+        } else if (lb_all && n_shards * lb_m >= k) {
+            __shared__ float s_gF;
+            float* fv = reinterpret_cast<float*>(hist);
+            const int nv = n_shards * lb_m, nv4 = (nv + 3) & ~3;   // (-inf padding never counts)
+            for (int i = threadIdx.x; i < nv4; i += SEL_THREADS)
+                fv[i] = i < nv ? lb_all[((int64_t)(i / lb_m) * gridDim.x + q) * lb_m + i % lb_m] : -INFINITY;
+            if (threadIdx.x == 0) s_gF = -INFINITY;
+            __syncthreads();
+            const f32x4* fv4 = reinterpret_cast<const f32x4*>(fv);
+            for (int i = threadIdx.x; i < nv; i += SEL_THREADS) {
+                const float v = fv[i];
+                if (!(v > -INFINITY)) continue;
+                int rank = 0;   // values ahead of v: larger ones, equal ones of a lower index
+#pragma unroll 4
+                for (int j = 0; j < nv4; j += 4) {   // (the same addresses in every lane: broadcast reads)
+                    const f32x4 w = fv4[j >> 2];
+                    rank += (w.x > v || (w.x == v && j < i)) ? 1 : 0;
+                    rank += (w.y > v || (w.y == v && j + 1 < i)) ? 1 : 0;
+                    rank += (w.z > v || (w.z == v && j + 2 < i)) ? 1 : 0;
+                    rank += (w.w > v || (w.w == v && j + 3 < i)) ? 1 : 0;
+                }
+                if (rank == k - 1) s_gF = v;
             }
             __syncthreads();
-            for (int u = 0; u < my_n; ++u) {
-                const Cand e = load_cand(u);
-                if (fkey(e.score) == tkey) {
-                    const int p = atomicAdd(&n_sel, 1);
-                    if (p < top_m) o[p] = lowered(e.score);
-                }
-            }
-        } else {
-            for (int u = 0; u < my_n; ++u) {
-                const Cand e = load_cand(u);
-                if (e.score > -INFINITY) o[atomicAdd(&n_sel, 1)] = lowered(e.score);
-            }
+            gF = s_gF;
+            __syncthreads();   // (hist is zeroed below)
         }
-        return;
     }
-
-    // the shards' common floor: rows below gband_lo cannot be among the global k best
-    const float gF = gfloor ? gfloor[q] : -INFINITY;
     float band_lo = -INFINITY;
     if (gF > -INFINITY) band_lo = nextafterf((float)((double)gF - 1.5 * eps * qn_hi), -INFINITY);
     float floor32 = tau[q];
     bool band_done = false;
-    if (n > k) {
+    const int kk = TOPM ? top_m : k;   // the rank the histogram pass looks for
+    float a_kk = -INFINITY;            // TOPM: a lower bound of the top_m-th largest scan score
+    if (n > kk) {
         // a_k, a lower bound of the k-th largest scan score: ONE histogram pass over 4096 LINEAR
         // bins between the smallest and the largest live candidate (the scores all sit just above
         // tau: binned by float exponent, as the sample select does, they fall into two or three
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
             if (sc > -INFINITY) atomicAdd(&hist[bin_of(sc)], 1);
         }
         __syncthreads();
-        coarse_find_bin(hist, k, aux);
+        coarse_find_bin(hist, kk, aux);
         const int kbin = aux[0];
         float a_k = INFINITY;
 #pragma unroll
@@ -697,9 +701,60 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
         if (lane == 0) fred[2][wave] = a_k;
         __syncthreads();
         a_k = fminf(fminf(fred[2][0], fred[2][1]), fminf(fred[2][2], fred[2][3]));
+        a_kk = a_k;
         const float band = (float)((double)a_k - 2.5 * eps * qn_hi);
         // (the float conversion may have rounded up); either bound rules a row out: the higher one
         band_lo = fmaxf(band_lo, nextafterf(band, -INFINITY));
+    }
+    if (TOPM) {
+        // the top_m largest scan scores, each as a lower bound of ||q|| x cosine of its row (the
+        // float conversion may round up: one step down).  The scores >= a_kk are the top_m and the
+        // few more that share the last histogram bin: collected in LDS, ranked by counting.
+        float* o = top_lb + (int64_t)q * top_m;
+        float* vals = reinterpret_cast<float*>(s_id);   // CAPB values
+        const double drop = eps * qn_hi;
+        auto lowered = [&](float sc) { return nextafterf((float)((double)sc - drop), -INFINITY); };
+        for (int i = threadIdx.x; i < top_m; i += SEL_THREADS) o[i] = -INFINITY;
+        for (int u = 0; u < my_n; ++u) {
+            const float sc = load_cand(u).score;
+            if (sc > -INFINITY && sc >= a_kk) {
+                const int p = atomicAdd(&n_sel, 1);
+                if (p < CAPB) vals[p] = sc;
+            }
+        }
+        __syncthreads();
+        const int c = n_sel;
+        if (c <= CAPB) {
+            for (int i = threadIdx.x; i < c; i += SEL_THREADS) {
+                const float v = vals[i];
+                int rank = 0;
+                for (int j = 0; j < c; ++j) {
+                    const float w = vals[j];
+                    rank += (w > v || (w == v && j < i)) ? 1 : 0;
+                }
+                if (rank < top_m) o[rank] = lowered(v);
+            }
+            return;
+        }
+        // (a tie wider than the LDS list at the top: the exact select, four passes)
+        __syncthreads();
+        if (threadIdx.x == 0) n_sel = 0;
+        __syncthreads();
+        const uint32_t tkey = block_radix_select_local(
+            [&](int u) { return fkey(load_cand(u).score); }, my_n, top_m, hist, bc);
+        for (int u = 0; u < my_n; ++u) {
+            const Cand e = load_cand(u);
+            if (fkey(e.score) > tkey) o[atomicAdd(&n_sel, 1)] = lowered(e.score);
+        }
+        __syncthreads();
+        for (int u = 0; u < my_n; ++u) {
+            const Cand e = load_cand(u);
+            if (fkey(e.score) == tkey) {
+                const int p = atomicAdd(&n_sel, 1);
+                if (p < top_m) o[p] = lowered(e.score);
+            }
+        }
+        return;
     }
     if (band_lo > -INFINITY) {
         // count and collect in one sweep; past CAPB rows only the count matters
@@ -789,9 +844,58 @@ __global__ __launch_bounds__(SEL_THREADS, 4) void select_band(
 // all land within 5 % of each other; 256-byte steps per row (half the occupancy) are 17 % slower.  The query is one more row of the shortlist: its dot
 // product with itself, in the same sequential order, is ||q||^2.
 constexpr int RR_WAVES = 2, RR_THREADS = 64 * RR_WAVES, RR_ROWS = 64;
-static size_t rescore_lds_bytes(int dim) {
-    return sizeof(float) * dim + sizeof(float4) * RR_WAVES * RR_ROWS * RS_STRIDE;
+static size_t rescore_lds_bytes(int dim) {   // the query as float64 | the waves' stage tiles
+    return sizeof(double) * dim + sizeof(float4) * RR_WAVES * RR_ROWS * RS_STRIDE;
 }
+// One pass of a wave over its (up to) 8 U staged rows: U row groups of 8 per 32-dim chunk, 16 / U
+// (at most 8) chunks of them in flight in registers.  Lanes of the groups that are not staged
+// compute on stale LDS words; their slots are beyond the list and nothing reads the result.
+// dim / 32 is a multiple of 8 for every row length the scans are built for.
+template <int U>
+//
+// dot += x * y as ONE v_fma_f64 per element: the product of two float32 values is exact in
+// float64 (48 significant bits), so fma(x, y, dot) rounds the same real number as the oracle's
+// separate multiply and add -- the same bits at half the float64 instructions; the query is
+// converted once per workgroup (q64), the rows as they are read.
+__device__ __forceinline__ double rescore_pass(const f32x4* (&rp)[8], f32x4* stage, const double* q64,
+                                               int nchunk, int lane, int lrow, int lch) {
+    constexpr int D = U >= 2 ? 16 / U : 8;
+    f32x4 nxt[D][U];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[dd][u] = rp[u][8 * dd];   // (nchunk >= D)
+    double dot = 0.0;
+#pragma unroll 1
+    for (int ck0 = 0; ck0 < nchunk; ck0 += D) {
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) {
+            const int ck = ck0 + dd;
+#pragma unroll
+            for (int u = 0; u < U; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[dd][u];
+            // (the last trips re-request the last chunk)
+            const int cn = ck + D < nchunk ? ck + D : nchunk - 1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[dd][u] = rp[u][8 * cn];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const f32x4* src = stage + lane * RS_STRIDE;
+            const double* qv = q64 + 32 * ck;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const f32x4 x = src[ch];
+                dot = __fma_rn((double)x.x, qv[4 * ch + 0], dot);
+                dot = __fma_rn((double)x.y, qv[4 * ch + 1], dot);
+                dot = __fma_rn((double)x.z, qv[4 * ch + 2], dot);
+                dot = __fma_rn((double)x.w, qv[4 * ch + 3], dot);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    return dot;
+}
+
 template <int NB>
 __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
     const float* __restrict__ docs, const double* __restrict__ dnorm, int dim, int64_t id_base,
@@ -804,7 +908,7 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
     if (NB == THR_DENSE_MAX_K ? ns > THR_DENSE_MAX_K : ns <= THR_DENSE_MAX_K) return;
     const float floor32 = __uint_as_float((uint32_t)sel_meta[4 * q + 1]);
     const bool overflow = sel_meta[4 * q + 2] != 0;
-    extern __shared__ float4 lds_sel[];  // [dim/4] query | RR_WAVES stage tiles
+    extern __shared__ float4 lds_sel[];  // [dim/2] the query as float64 | RR_WAVES stage tiles
     __shared__ double s_s[NB], o_s[NB];
     __shared__ int64_t s_id[NB], o_id[NB];
     __shared__ double s_qn;
@@ -812,8 +916,8 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double eq = qerr ? (double)qerr[q] : 0.0;
     const double eps = eps32 + doc_relerr * (1.0 + eq) + eq;
-    for (int i = threadIdx.x; i < dim / 4; i += RR_THREADS)
-        lds_sel[i] = reinterpret_cast<const float4*>(queries + (int64_t)q * dim)[i];
+    double* q64 = reinterpret_cast<double*>(lds_sel);
+    for (int i = threadIdx.x; i < dim; i += RR_THREADS) q64[i] = (double)queries[(int64_t)q * dim + i];
     for (int i = threadIdx.x; i < NB; i += RR_THREADS) {
         s_s[i] = o_s[i] = -INFINITY;
         s_id[i] = i < ns ? (int64_t)sel_rows[(int64_t)q * SEL_BIG_BAND + i] : INT64_MAX;
@@ -825,9 +929,8 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
     // ---- float64 rescoring: SEQUENTIAL sums (the oracle's contract), one lane per row ----
     // (native vectors, not HIP's float4 class: see dense_scan_mfma2 -- a float4 array that is
     // copied into LDS is demoted to scratch memory)
-    f32x4* stage = reinterpret_cast<f32x4*>(lds_sel + dim / 4) + wave * (RR_ROWS * RS_STRIDE);
+    f32x4* stage = reinterpret_cast<f32x4*>(lds_sel + dim / 2) + wave * (RR_ROWS * RS_STRIDE);
     const f32x4* docs4 = reinterpret_cast<const f32x4*>(docs);
-    const f32x4* qv4 = reinterpret_cast<const f32x4*>(lds_sel);
     const int lrow = lane >> 3, lch = lane & 7;
     const int cpr = dim / 4, nchunk = dim / 32;
     const f32x4* q4 = reinterpret_cast<const f32x4*>(queries + (int64_t)q * dim);
@@ -836,6 +939,8 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
     for (int b0 = 0; b0 <= ns; b0 += RR_WAVES * RR_ROWS) {
         // slot of (wave, staged row r) is b0 + wave + RR_WAVES r; slot ns is the query itself;
         // a lane loads 16 bytes of rows lrow + 8 u (8 lanes per 128-byte line)
+        const int rem = ns - b0 - wave;          // this wave's slots of the pass: r <= rem / RR_WAVES
+        if (rem < 0) continue;                   // (wave-uniform)
         const f32x4* rp[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -844,39 +949,15 @@ __global__ __launch_bounds__(RR_THREADS, 3) void rescore_rank(
             rp[u] = (j < ns ? docs4 + s_id[j] * cpr : q4) + lch;
         }
         const int jm = b0 + wave + RR_WAVES * lane;  // this lane's own slot
-        f32x4 nxt[RS_DEPTH][8];
-#pragma unroll
-        for (int dd = 0; dd < RS_DEPTH; ++dd)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) nxt[dd][u] = rp[u][8 * dd];   // (nchunk >= RS_DEPTH)
-        double dot = 0.0;
-#pragma unroll 1
-        for (int ck0 = 0; ck0 < nchunk; ck0 += RS_DEPTH) {
-#pragma unroll
-            for (int dd = 0; dd < RS_DEPTH; ++dd) {
-                const int ck = ck0 + dd;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) stage[(lrow + 8 * u) * RS_STRIDE + lch] = nxt[dd][u];
-                // (the last trips re-request the last chunk)
-                const int cn = ck + RS_DEPTH < nchunk ? ck + RS_DEPTH : nchunk - 1;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) nxt[dd][u] = rp[u][8 * cn];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const f32x4* src = stage + lane * RS_STRIDE;
-                const f32x4* qv = qv4 + 8 * ck;
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    const f32x4 x = src[ch], y = qv[ch];
-                    dot = __dadd_rn(dot, __dmul_rn((double)x.x, (double)y.x));
-                    dot = __dadd_rn(dot, __dmul_rn((double)x.y, (double)y.y));
-                    dot = __dadd_rn(dot, __dmul_rn((double)x.z, (double)y.z));
-                    dot = __dadd_rn(dot, __dmul_rn((double)x.w, (double)y.w));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+        // A short list (a shard under the common floor rescores ~k / G rows, a top-10 search ~12)
+        // fills only the first row groups of the wave: it stages those alone and keeps more
+        // chunks of them in flight instead -- the pass is a chain of memory round trips.
+        const int groups = rem / RR_WAVES / 8 + 1;
+        double dot;
+        if (groups <= 1) dot = rescore_pass<1>(rp, stage, q64, nchunk, lane, lrow, lch);
+        else if (groups <= 2) dot = rescore_pass<2>(rp, stage, q64, nchunk, lane, lrow, lch);
+        else if (groups <= 4) dot = rescore_pass<4>(rp, stage, q64, nchunk, lane, lrow, lch);
+        else dot = rescore_pass<8>(rp, stage, q64, nchunk, lane, lrow, lch);
         if (jm < ns) s_s[jm] = dot;               // the raw dot product for now
         else if (jm == ns) s_qn = __dsqrt_rn(dot);  // ||q||
     }
@@ -1507,7 +1588,8 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
                           int n_queries, int k, int kprime, double* out_scores, int64_t* out_ids,
                           int32_t* out_counts, uint32_t* out_flags, char* ws, hipStream_t st,
                           const int32_t* doc_coll, const int32_t* query_coll, int phase = PIPE_ALL,
-                          const float* gfloor = nullptr, float* top_lb = nullptr, int top_m = 0) {
+                          const float* gfloor = nullptr, float* top_lb = nullptr, int top_m = 0,
+                          const float* lb_all = nullptr, int n_shards = 0) {
     float* tau = (float*)(ws + p.off_tau);
     const bool h = p.kind == KIND_F16;
     float* qerr = h ? (float*)(ws + p.off_qerr) : nullptr;
@@ -1579,13 +1661,14 @@ static int dense_pipeline(const DensePlan& p, const float* docs, const _Float16*
         hipLaunchKernelGGL(select_band<true>, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st,
                            dim, queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32,
                            doc_relerr, qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll,
-                           sel_rows, sel_meta, (const float*)nullptr, top_lb, top_m);
+                           sel_rows, sel_meta, (const float*)nullptr, (const float*)nullptr, 0, 0, top_lb,
+                           top_m);
         return launch_status();
     }
     hipLaunchKernelGGL(select_band<false>, dim3(n_queries), dim3(SEL_THREADS), band_lds_bytes(dim), st,
                        dim, queries, tau, cnt, cand, tcnt, p.tile_cap, p.qtile, k, kprime, eps32,
                        doc_relerr, qerr, nseg, nseg ? CAND_CAP / nseg : 0, doc_coll, query_coll,
-                       sel_rows, sel_meta, gfloor, (float*)nullptr, 0);
+                       sel_rows, sel_meta, gfloor, lb_all, n_shards, top_m, (float*)nullptr, 0);
     if ((rc = launch_status())) return rc;
     hipLaunchKernelGGL(rescore_rank<THR_DENSE_MAX_K>, dim3(n_queries), dim3(RR_THREADS),
                        rescore_lds_bytes(dim), st, docs, dnorm, dim, id_base, queries, k, eps32,
@@ -1749,6 +1832,7 @@ extern "C" int thr_dense_finish_f16(const float* docs, const uint16_t* docs16, d
                                     int dim, int64_t id_base, const float* queries, int n_queries,
                                     int k, int kprime, const int32_t* doc_coll,
                                     const int32_t* query_coll, const float* gfloor,
+                                    const float* top_lb_all, int n_shards, int m,
                                     double* out_scores, int64_t* out_ids, int32_t* out_counts,
                                     uint32_t* out_flags, void* workspace, size_t workspace_bytes,
                                     thr_stream_t stream) {
@@ -1757,12 +1841,15 @@ extern "C" int thr_dense_finish_f16(const float* docs, const uint16_t* docs16, d
                            out_flags, workspace, n_docs, n_queries, k, kprime);
     if (rc) return rc;
     if ((rc = f16_args_ok(docs, docs16, doc_rel_err, n_docs, dim, n_queries, doc_coll, query_coll))) return rc;
+    THR_RETURN_IF(gfloor && top_lb_all, THR_ERR_INVALID);
+    THR_RETURN_IF(top_lb_all && (n_shards <= 0 || m <= 0), THR_ERR_INVALID);
+    THR_RETURN_IF(top_lb_all && (int64_t)n_shards * m > CS_BINS, THR_ERR_CAPACITY);
     const DensePlan p = make_plan(n_docs, n_queries, kprime, KIND_F16, dim, docs16 != nullptr);
     THR_RETURN_IF(workspace_bytes < p.total, THR_ERR_WORKSPACE);
     return dense_pipeline(p, docs, reinterpret_cast<const _Float16*>(docs16), doc_rel_err, dnorm,
                           inv_norm, n_docs, dim, id_base, queries, n_queries, k, kprime, out_scores,
                           out_ids, out_counts, out_flags, (char*)workspace, (hipStream_t)stream,
-                          doc_coll, query_coll, PIPE_FINISH, gfloor);
+                          doc_coll, query_coll, PIPE_FINISH, gfloor, nullptr, m, top_lb_all, n_shards);
 }
 
 extern "C" int thr_dense_scan_probe(const float* docs, const float* inv_norm, int64_t n_docs,

@@ -355,10 +355,9 @@ class GpuIndex:
                 lb = N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm,
                                            queries, kp, floor_width(k, n_shards), ws,
                                            doc_coll=dc, query_coll=qc)
-                gfloor = N.dense_floor(exchange(lb), k)
                 S, I, cnt, flg = N.dense_finish_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
-                                                    self.inv_norm, queries, k, kp, gfloor, self.doc_base,
-                                                    ws, doc_coll=dc, query_coll=qc)
+                                                    self.inv_norm, queries, k, kp, None, self.doc_base,
+                                                    ws, doc_coll=dc, query_coll=qc, lb_all=exchange(lb))
             else:
                 S, I, cnt, flg = N.dense_topk_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
                                                   self.inv_norm, queries, k, kp, self.doc_base, ws,
@@ -399,13 +398,15 @@ class GpuIndex:
         return N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm, queries, kp,
                                      floor_width(k, n_shards), ws, doc_coll=dc, query_coll=qc)
 
-    def dense_finish(self, queries: torch.Tensor, k: int, gfloor: Optional[torch.Tensor],
-                     kprime: Optional[int] = None, rescue: bool = True, collections=None):
-        """-> (scores, ids, counts, flags BEFORE the rescue, n_rescued device int32[1] or 0)."""
+    def dense_finish(self, queries: torch.Tensor, k: int, gfloor: Optional[torch.Tensor] = None,
+                     kprime: Optional[int] = None, rescue: bool = True, collections=None,
+                     lb_all: Optional[torch.Tensor] = None):
+        """-> (scores, ids, counts, flags BEFORE the rescue, n_rescued device int32[1] or 0).
+        The floor: gfloor [nq], or the gathered bounds lb_all [n_shards, nq, m] themselves."""
         queries, kp, ws, dc, qc = self._f16_call(queries, k, kprime, collections)
         S, I, cnt, flg = N.dense_finish_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
                                             self.inv_norm, queries, k, kp, gfloor, self.doc_base, ws,
-                                            doc_coll=dc, query_coll=qc)
+                                            doc_coll=dc, query_coll=qc, lb_all=lb_all)
         flags0 = flg.clone()
         n_rescued = 0
         if rescue:
