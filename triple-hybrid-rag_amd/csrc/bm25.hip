@@ -2538,7 +2538,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     hipError_t e = hipMemsetAsync(ws + L.off_ctl, 0, L.off_tot - L.off_ctl, st);   // ctl + theta
     if (e != hipSuccess) return (int)e;
 #ifdef BM_STAMPS
-    hipMemsetAsync(ws + L.off_stamps, 0, sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap), st);
+    (void)hipMemsetAsync(ws + L.off_stamps, 0, sizeof(unsigned long long) * (3 * 4096 * (BM_NSTAMP + 1) + 8 * (size_t)L.cap), st);
 #endif
     static int small = -1, use_dense = 1, walk_div = 64, fuse_div = 8, use_wave = 1;
     if (small < 0) {
@@ -2617,10 +2617,10 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                            );
 #ifdef BM_STAMPS
         {
-            hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(st);
             const int nw = wgrid_w * WW_WAVES;
             std::vector<unsigned long long> h((size_t)nw * 16);
-            hipMemcpy(h.data(), ws + L.off_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), ws + L.off_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             double tot[16] = {0};
             double mx = 0;
             for (int w = 0; w < nw; ++w) {
@@ -2667,11 +2667,11 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
                                                "bloom build", "singles listed", "singles scored", "work list / boot select", "compact/advance", "finish",
                                                "mask / acc fill", "slot scan / middle search", "#acc passes", "#mask passes",
                                                "#postings masked", "#survivors", "#phase2 rounds", ""};
-        hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st);
         for (int pass = 0; pass < (dslot ? 3 : 1); ++pass) {
             const int g_n = pass == 1 ? bm_num_cus() * 2 : grid;
             std::vector<unsigned long long> h((size_t)g_n * (BM_NSTAMP + 1));
-            hipMemcpy(h.data(), d_stamps + (size_t)pass * 4096 * (BM_NSTAMP + 1), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), d_stamps + (size_t)pass * 4096 * (BM_NSTAMP + 1), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             double tot[BM_NSTAMP + 1] = {0};
             for (int g = 0; g < g_n; ++g)
                 for (int i = 0; i <= BM_NSTAMP; ++i) tot[i] += (double)h[(size_t)g * (BM_NSTAMP + 1) + i];
@@ -2686,10 +2686,10 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         }
         if (dslot) {   // the sweep items one by one: when each started and ended (cycles since the first), its passes and survivors
             int h_ctl[8];
-            hipMemcpy(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost);
             const int ns = h_ctl[5];
             std::vector<unsigned long long> lg((size_t)4 * (ns > 0 ? ns : 1));
-            hipMemcpy(lg.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1), lg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(lg.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1), lg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int i = 0; i < ns; ++i) {
                 if (lg[4 * i + 1] < t0) t0 = lg[4 * i + 1];
@@ -2699,7 +2699,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
             if (getenv("THR_BM25_ITEM_LOG")) {
                 const int ni = h_ctl[0];
                 std::vector<unsigned long long> wl((size_t)4 * (ni > 0 ? ni : 1));
-                hipMemcpy(wl.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1) + 4 * (size_t)L.cap, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(wl.data(), d_stamps + (size_t)3 * 4096 * (BM_NSTAMP + 1) + 4 * (size_t)L.cap, wl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
                 for (int i = 0; i < ni; ++i)
                     if (wl[4 * i + 2])
                         fprintf(stderr, "[walk] %d q %llu slice %llu dp %llu nt %llu postings %llu cycles %llu passes %llu\n", i, wl[4 * i] >> 32,
