@@ -190,3 +190,42 @@ def test_config3_config4_one_shard_of_the_10m_corpus(T, rank):
         for a in range(len(order)):   # identical wherever the oracle's scores are > 2e-4 apart
             if (a == 0 or es[a - 1] - es[a] > 2e-4) and (a == len(order) - 1 or es[a] - es[a + 1] > 2e-4):
                 assert int(ids4[i][a]) == f100[i][order[a]]
+
+
+def test_config3_dense_channel_eight_shards_with_the_shard_floor(T):
+    """BASELINE configs[3]'s dense channel at its full size: 10M x 768 as the 8 document shards of
+    1.25M rows, all resident on this GPU.  The shard-floor path (thr_dense_shortlist_f16 -> the
+    gathered bounds -> thr_dense_finish_f16 -> thr_merge_topk) against every shard ranking a
+    top-100 of its own: the same bits for every query; against the oracle (per-shard fast path,
+    merged on the host under (score desc, id asc)) for the first 16; a shard rescores ~k / 8 rows."""
+    from triple_hybrid_rag_amd import synth
+    from triple_hybrid_rag_amd.distributed import shard_range
+    n_global, world, nq, k, n_or = 10_000_000, 8, 256, 100, 16
+    q = synth.dense_queries(nq, D, n_global)
+    shards, oracle = [], []
+    for r in range(world):
+        lo, hi = shard_range(n_global, r, world)
+        x = synth.dense_rows(lo, hi - lo, D)
+        shards.append(T.GpuIndex(doc_base=lo).set_dense(x))
+        assert shards[-1].shortlist == "f16"
+        oracle.append(O.dense_topk_fast(x, q[:n_or], k, doc_id_base=lo))
+        del x
+    qd = dev(q)
+    classic = [ix.dense_search(qd, k, sync=False) for ix in shards]
+    S0, I0, _ = T._native.merge_topk(torch.stack([c[0] for c in classic]), torch.stack([c[1] for c in classic]), k)
+    lbs = torch.stack([ix.dense_shortlist(qd, k, world) for ix in shards])
+    outs = []
+    for ix in shards:
+        ix.dense_shortlist(qd, k, world)      # (a shard's finish reads the lists ITS shortlist call left)
+        outs.append(ix.dense_finish(qd, k, lb_all=lbs))
+    S1, I1, c1 = T._native.merge_topk(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), k)
+    assert torch.equal(S0, S1) and torch.equal(I0, I1)
+    assert sum(int(o[4]) for o in outs) == 0 and sum(int(c[3]) for c in classic) == 0
+    cnts = torch.stack([o[2] for o in outs]).cpu().numpy()
+    assert np.all(cnts.sum(0) >= k) and cnts.mean() < 2.0 * k / world, cnts.mean()
+    assert all(bool(torch.all(o[3] & 1)) for o in outs), "every shard's list certified by the shortlist path"
+    S1, I1 = S1.cpu().numpy(), I1.cpu().numpy()
+    for i in range(n_or):
+        pairs = sorted(((-float(s), int(d)) for Sd, Id in oracle for s, d in zip(Sd[i], Id[i])))[:k]
+        assert [d for _, d in pairs] == list(I1[i]), f"query {i}: ids differ from the oracle's merged top-{k}"
+        assert [-s for s, _ in pairs] == list(S1[i]), f"query {i}: scores differ (bits)"
