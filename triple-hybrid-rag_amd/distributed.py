@@ -142,8 +142,17 @@ class ShardedIndex:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # the dense channel split around one more (small) exchange, so that a shard rescores its
-        # share of the global top-k instead of a top-k of its own (GpuIndex.dense_search)
+        # share of the global top-k instead of a top-k of its own (GpuIndex.dense_search).  Every
+        # rank must make the same collective calls, and which scan a shard runs depends on ITS rows
+        # (set_dense falls back to the float32 scan for rows outside the float16 range): the
+        # shards agree once, here, and the floor is used only if all of them can
         self.floor = floor
+        if self.world > 1 and floor:
+            ok = torch.tensor([1 if getattr(local, "shortlist", None) in ("f16", "f16-inline") else 0],
+                              dtype=torch.int32,
+                              device="cpu" if dist.get_backend(group) == "gloo" else local.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            self.floor = bool(int(ok.item()))
 
     def _floor_exchange(self):
         if self.world == 1 or not self.floor or self.local.shortlist not in ("f16", "f16-inline"):

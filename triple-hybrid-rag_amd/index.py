@@ -39,7 +39,7 @@ def floor_width(k: int, n_shards: int) -> int:
     share of the k best, at least 16 -- the k-th largest of the n_shards * m values is then close
     to the true k-th score unless one shard holds most of the k best."""
     m = max(16, 2 * -(-k // max(1, n_shards)))
-    return max(1, min(m, N.THR_DENSE_MAX_K, 8192 // max(1, n_shards)))
+    return max(1, min(m, N.THR_DENSE_MAX_K, 4096 // max(1, n_shards)))   # (n_shards * m values fit the band kernel's LDS)
 
 
 @dataclass
