@@ -1312,6 +1312,39 @@ def test_dense_shard_floor_ties_nulls_skew_and_collections(T):
     assert cnt[4] == 0
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_dense_shard_floor_random_shapes(T, seed):
+    """Random corpus sizes (uneven shards, some below the sampling threshold), row lengths, shard
+    counts, k from 1 to 200, clustered rows, NULL rows and a collection filter on half the draws:
+    the merged shard-floor result is the oracle's top-k."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([512, 768, 1024]))
+    g = int(rng.choice([2, 3, 5, 8]))
+    k = int(rng.choice([1, 10, 50, 100, 128, 200]))
+    n = int(rng.integers(3000, 70000))
+    nq = int(rng.integers(1, 40))
+    x, _ = rand_docs(n, d, 2000 + seed)
+    c0 = int(rng.integers(0, n - 600))
+    x[c0:c0 + 500] = x[c0] + 0.02 * x[c0:c0 + 500]          # a cluster of near-duplicates on one shard
+    x[rng.integers(0, n, 20)] = 0
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[0] = x[c0] * 0.7
+    coll = qc = None
+    if seed % 2:
+        coll = rng.integers(0, 6, n).astype(np.int32)
+        qc = rng.integers(-1, 7, nq).astype(np.int32)          # (6: a collection nobody has)
+    (S, I, cnt), cnts, flags, nres, gfloor = _floor_search(T, x, q, k, g, "f16", coll, qc)
+    S, I, cnt = S.cpu().numpy(), I.cpu().numpy(), cnt.cpu().numpy()
+    dn = O.doc_norms_f64(x)
+    for i in range(nq):
+        sc = O.cosine_scores_f64(x, q[i], dn)
+        if qc is not None and qc[i] != -1:
+            sc[coll != qc[i]] = -np.inf
+        ts, ti = O.topk_desc(sc, k)
+        assert cnt[i] == len(ti) and np.array_equal(I[i, :len(ti)], ti), (seed, i, d, g, k, n)
+        assert np.array_equal(S[i, :len(ti)], ts), (seed, i)
+
+
 def test_dense_floor_kernel_known_answers(T):
     """thr_dense_floor alone: k-th largest of the shards' values, duplicates counted, -inf when
     fewer than k are finite."""
