@@ -1363,6 +1363,25 @@ def test_dense_floor_kernel_known_answers(T):
         T._native.dense_floor(dev(np.zeros((65, 2, 128), dtype=np.float32)), 10)
 
 
+def test_dense_finish_needs_its_shortlist(T):
+    """dense_finish works on the candidate lists a dense_shortlist call left in the index's
+    workspace: anything in between, or another batch shape, is refused instead of ranking stale lists."""
+    x, rng = rand_docs(20000, 768, 77)
+    q = rng.standard_normal((5, 768)).astype(np.float32)
+    idx = T.GpuIndex().set_dense(x)
+    with pytest.raises(T._native.NativeError):
+        idx.dense_finish(dev(q), 10)
+    idx.dense_shortlist(dev(q), 10, 4)
+    S, I, cnt, _, _ = idx.dense_finish(dev(q), 10)              # no floor: thr_dense_topk_f16's result
+    Se, Ie, cnte = CO.dense_topk_exact(x, q, 10)
+    assert_topk_equal(S, I, cnt, Se, Ie, cnte, "finish-without-floor")
+    with pytest.raises(T._native.NativeError):
+        idx.dense_finish(dev(q[:3]), 10)                          # another batch
+    idx.dense_search(dev(q), 10)
+    with pytest.raises(T._native.NativeError):
+        idx.dense_finish(dev(q), 10)                              # the lists were overwritten
+
+
 def _sharded_worker(rank, world, port, n, d, out_dir):
     import os
     import sys

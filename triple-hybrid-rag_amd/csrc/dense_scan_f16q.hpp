@@ -229,7 +229,6 @@ __device__ __forceinline__ void qsx_steps(f32x4 (&a)[Q_RING], const f32x4 (&bq)[
         qsx_steps<S + 1, HS, K0, KS, PER, SHAPE>(a, bq, acc, abase, issue_piece);
     }
 }
-#undef QS_RD
 
 // the emit of one accumulator register (a struct member, not a lambda: its store is inline asm).
 // A lane's candidate segment is addressed as a 32-bit byte offset from `cand` (one SGPR pair for
@@ -267,6 +266,40 @@ struct QEmit {
         }
     }
 };
+
+// qsx_steps with the emit of the PREVIOUS row tile's accumulators threaded through it (the 4-wave
+// kernel below, MODE_FILTER): a block of that kernel has ONE wave per SIMD, so while a wave runs
+// its epilogue nothing feeds the SIMD's matrix pipe -- the stamps put that at a quarter of a half
+// tile.  Here the 16 accumulator registers of tile i - 1 are compared / stored one at a time
+// between the MFMAs of tile i (8 per half tile, evenly spaced): an MFMA occupies the pipe for
+// 16 cycles after it issues, which is what one register's compare-and-branch takes to issue.
+template <int S, int HS, int K0, int KS, int PER, int SHAPE, int HF, typename Issue>
+__device__ __forceinline__ void qsx_steps_pe(f32x4 (&a)[Q_RING], const f32x4 (&bq)[KS], QAcc<SHAPE>& acc,
+                                             uint32_t abase, Issue& issue_piece, QEmit<SHAPE>& em,
+                                             const QAcc<SHAPE>& prv, uint32_t row_prv, int lane) {
+    if constexpr (S < HS) {
+        constexpr int left = HS - S - 1 < Q_RING - 1 ? HS - S - 1 : Q_RING - 1;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % Q_RING]) : "n"(left) : "memory");
+        if constexpr (SHAPE == 32) {
+            acc.v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[S % Q_RING]),
+                                                           __builtin_bit_cast(half8, bq[K0 + S]), acc.v, 0, 0, 0);
+        } else {
+            constexpr int k32 = (K0 + S) / 2, ra = S & 1;
+            acc.t[2 * ra] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[k32]), acc.t[2 * ra], 0, 0, 0);
+            acc.t[2 * ra + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[KS / 2 + k32]),
+                acc.t[2 * ra + 1], 0, 0, 0);
+        }
+        if constexpr (S + Q_RING < HS) QS_RD(a[S % Q_RING], S + Q_RING);
+        constexpr int every = HS / PER;
+        if constexpr (S % every == 1 && S / every < PER) issue_piece(std::integral_constant<int, S / every>{});
+        constexpr int ev_e = HS / 8;   // (HS is 8, 12 or 16 k-steps times the pieces per step: a multiple of 8)
+        if constexpr (S % ev_e == ev_e - 1 && S / ev_e < 8) em.template one<8 * HF + S / ev_e>(prv, row_prv, lane);
+        qsx_steps_pe<S + 1, HS, K0, KS, PER, SHAPE, HF>(a, bq, acc, abase, issue_piece, em, prv, row_prv, lane);
+    }
+}
+#undef QS_RD
 
 // PROF: diagnostic build (thr_dense_scan_stamps_f16): s_memtime stamps around the phases of the
 // half-tile loop, summed per wave into stamps[(block * 4 + wave) * 8 + {0: wait for the own DMA
@@ -375,6 +408,60 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
             buf = buf + 1 == NB ? 0 : buf + 1;
         }
     }
+    // MODE_FILTER: the emit of a row tile runs between the MFMAs of the NEXT one (qsx_steps_pe), out
+    // of the other of two accumulator sets; the first tile "emits" a set of -inf (a compare and a
+    // branch per register), the last tile's set is emitted after the loop.  Same barriers, same
+    // DMA order and wait counts per half tile as below.
+    // (Only where a block is alone on its CU -- dim 1024, one wave per SIMD: with two blocks per CU
+    // the other block's MFMAs already cover an epilogue, and the second accumulator set does not fit
+    // the 256-register budget there.)
+    if constexpr (MODE == MODE_FILTER && !PROF && C::PER_CU == 1) {
+        A acc2[2];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            if constexpr (SHAPE == 32) acc2[1].v[x] = -INFINITY;
+            else acc2[1].t[x >> 2][x & 3] = -INFINITY;
+        }
+        uint32_t row_of[2] = {0u, 0u};
+#define QS_HALF_PE(hf, CUR, PRV)                                                                   \
+    {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
+        __builtin_amdgcn_s_barrier();                                                              \
+        const int nbuf = buf == 0 ? NB - 1 : buf - 1; /* half tile j-1's buffer */                 \
+        const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
+        auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
+        const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
+        f32x4 a[Q_RING];                                                                           \
+        qs_fill<0, HS>(a, abase);                                                                  \
+        qsx_steps_pe<0, HS, (hf) * HS, KS, PER, SHAPE, (hf)>(a, bq, acc2[CUR], abase, issue_piece, \
+                                                            em, acc2[PRV], row_of[PRV], lane);     \
+        buf = buf + 1 == NB ? 0 : buf + 1;                                                         \
+    }
+        const int64_t n_it = idle ? 0 : n_mine;
+        int64_t i = 0;
+#pragma unroll 1
+        for (; i + 1 < n_it; i += 2) {
+            acc2[0].zero();
+            QS_HALF_PE(0, 0, 1)
+            QS_HALF_PE(1, 0, 1)
+            row_of[0] = (uint32_t)((first + i * step) * tile_stride * 32);
+            ++i;
+            acc2[1].zero();
+            QS_HALF_PE(0, 1, 0)
+            QS_HALF_PE(1, 1, 0)
+            row_of[1] = (uint32_t)((first + i * step) * tile_stride * 32);
+            --i;
+        }
+        if (i < n_it) {   // an odd tile left: into set 0, emitting set 1; then set 0 itself
+            acc2[0].zero();
+            QS_HALF_PE(0, 0, 1)
+            QS_HALF_PE(1, 0, 1)
+            em.template all<0>(acc2[0], (uint32_t)((first + i * step) * tile_stride * 32), lane);
+        } else if (n_it > 0) {
+            em.template all<0>(acc2[1], row_of[1], lane);
+        }
+#undef QS_HALF_PE
+    } else {
     // one trip = one row tile = two half tiles (the accumulators run through both)
 #pragma unroll 1
     for (int64_t i = 0; i < (idle ? 0 : n_mine); ++i) {
@@ -438,6 +525,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
             em.template all<0>(acc, (uint32_t)(t * tile_stride * 32), lane);
         }
         stamp(4);
+    }
     }
     // nothing may still be landing in LDS when the block retires
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -324,6 +324,7 @@ class GpuIndex:
         sequence of calls.  Used by the f16 scans only."""
         queries = self._t(queries, torch.float32)
         nq = queries.shape[0]
+        self._shortlist_of = None     # (the workspace's candidate lists are about to be overwritten)
         if self.shortlist == "f16":
             # one call of the copy scan takes at most dense_f16_max_queries queries (its
             # candidate-segment offsets are 32 bits): larger batches go through in pieces
@@ -395,8 +396,12 @@ class GpuIndex:
     def dense_shortlist(self, queries: torch.Tensor, k: int, n_shards: int, kprime: Optional[int] = None,
                         collections=None) -> torch.Tensor:
         queries, kp, ws, dc, qc = self._f16_call(queries, k, kprime, collections)
-        return N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm, queries, kp,
-                                     floor_width(k, n_shards), ws, doc_coll=dc, query_coll=qc)
+        self._shortlist_of = None
+        lb = N.dense_shortlist_f16(self.docs, self.docs16, self.doc_rel_err, self.inv_norm, queries, kp,
+                                   floor_width(k, n_shards), ws, doc_coll=dc, query_coll=qc)
+        # what the candidate lists in the workspace belong to: dense_finish refuses anything else
+        self._shortlist_of = (queries.shape[0], kp, collections is not None, ws.data_ptr())
+        return lb
 
     def dense_finish(self, queries: torch.Tensor, k: int, gfloor: Optional[torch.Tensor] = None,
                      kprime: Optional[int] = None, rescue: bool = True, collections=None,
@@ -404,6 +409,10 @@ class GpuIndex:
         """-> (scores, ids, counts, flags BEFORE the rescue, n_rescued device int32[1] or 0).
         The floor: gfloor [nq], or the gathered bounds lb_all [n_shards, nq, m] themselves."""
         queries, kp, ws, dc, qc = self._f16_call(queries, k, kprime, collections)
+        if getattr(self, "_shortlist_of", None) != (queries.shape[0], kp, collections is not None, ws.data_ptr()):
+            raise N.NativeError("dense_finish: the workspace does not hold the candidate lists of a matching "
+                                "dense_shortlist call (same batch size, k, collections; no other dense "
+                                "search on this index in between)")
         S, I, cnt, flg = N.dense_finish_f16(self.docs, self.docs16, self.doc_rel_err, self.dnorm,
                                             self.inv_norm, queries, k, kp, gfloor, self.doc_base, ws,
                                             doc_coll=dc, query_coll=qc, lb_all=lb_all)
