@@ -53,11 +53,11 @@ def test_host_side_planning_functions():
     """Sizes and the query-tile choice are pure host arithmetic (no launch)."""
     N = T._native
     N.load()
-    # f16 copy scan: 32 queries per wave (their B operands live in registers); 8 waves per
-    # block, 4 at dim 1024 (256 B-operand registers: one wave per SIMD)
+    # f16 copy scan: 32 queries per wave (their B operands live in registers), 8 waves per block;
+    # at dim 1024 4 waves (one per SIMD) of 48 queries -- 384 B-operand registers each
     assert N.dense_f16_query_tile(768, True, 1024) == 256
     assert N.dense_f16_query_tile(512, True, 1536) == 256
-    assert N.dense_f16_query_tile(1024, True, 1536) == 128
+    assert N.dense_f16_query_tile(1024, True, 1536) == 192
     assert N.dense_f16_query_tile(768, False, 1536) == 64     # in-flight rounding: transpose tiles
     assert N.dense_f16_query_tile(1024, False, 1536) == 32
     assert N.dense_f16_query_tile(640, True, 64) == 0         # no f16 kernel at that dim

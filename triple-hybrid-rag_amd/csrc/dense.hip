@@ -1243,7 +1243,7 @@ static bool qreg_staggered(int dim) {
     }
     return !forced_q && dim <= 768;
 }
-static int qreg_waves(int dim) { return qreg_staggered(dim) ? 8 : 4; }   // 32 queries per wave
+static int qreg_waves(int dim) { return qreg_staggered(dim) ? 8 : 4; }   // qreg_qw queries per wave
 // MFMA shape of the staggered scan and therefore of the copy / query images: 16 (16x16x32, the
 // default: 2.50 ms against 2.67 ms per 2048 x 1M x 768 launch) or 32 (32x32x16,
 // THR_DENSE_MFMA=32).  Read once: the copy's layout depends on it.
@@ -1256,12 +1256,22 @@ static int qreg_shape(int dim) {
     (void)dim;   // (both register-resident kernels take either shape)
     return v;
 }
+// queries per wave: 32, or 48 at dim 1024 with the 16x16x32 shape (dense_scan_f16q<1024, .., 48>:
+// three 16-query blocks per wave, 192 queries per CU; THR_DENSE_QW=32 keeps the 32-query kernel for A/B)
+static int qreg_qw(int dim) {
+    static int forced32 = -1;
+    if (forced32 < 0) {
+        const char* e = getenv("THR_DENSE_QW");
+        forced32 = (e && atoi(e) == 32) ? 1 : 0;
+    }
+    return (dim == 1024 && !qreg_staggered(dim) && qreg_shape(dim) == 16 && !forced32) ? 48 : 32;
+}
 constexpr int QREG_MAX_SEG = 1024;
 // The register-resident scans address a lane's candidate segment with a 32-bit byte offset from
 // the start of the candidate area ((q * CAND_CAP + segment start) * sizeof(Cand)): a batch may
 // hold as many (padded) queries as keep every offset below 2^32.
 static int qreg_max_queries(int dim) {
-    const int qt = 32 * qreg_waves(dim);
+    const int qt = qreg_qw(dim) * qreg_waves(dim);
     const int64_t m = (int64_t)UINT32_MAX / ((int64_t)CAND_CAP * (int64_t)sizeof(Cand));
     return (int)(m / qt * qt);
 }
@@ -1274,7 +1284,7 @@ static DensePlan make_plan(int64_t n_docs, int n_queries, int kprime, int kind =
     p.qreg = p.packed;
     p.nq = (kind == KIND_F16 && !p.packed) ? f16_pick_nq(dim) : 1;
     p.row_bits = (kind == KIND_F16 && !p.qreg) ? ROW_BITS_F16 : ROW_BITS;
-    p.qtile = p.qreg ? 32 * qreg_waves(dim)
+    p.qtile = p.qreg ? qreg_qw(dim) * qreg_waves(dim)
               : kind == KIND_F16 ? 32 * p.nq : MF_QT;
     p.unit = MF_ROWS;
     p.ntiles = (n_queries + p.qtile - 1) / p.qtile;
@@ -1538,7 +1548,11 @@ static int launch_scan_f16q(int dim, const _Float16* rows16, const _Float16* qfr
     switch (dim) {
         case 512: if (shape == 16) THR_Q_LAUNCH(512, 16) else THR_Q_LAUNCH(512, 32) break;
         case 768: if (shape == 16) THR_Q_LAUNCH(768, 16) else THR_Q_LAUNCH(768, 32) break;
-        case 1024: if (shape == 16) THR_Q_LAUNCH(1024, 16) else THR_Q_LAUNCH(1024, 32) break;
+        case 1024:
+            if (shape == 16 && qreg_qw(dim) == 48) THR_Q_LAUNCH(1024, 48)
+            else if (shape == 16) THR_Q_LAUNCH(1024, 16)
+            else THR_Q_LAUNCH(1024, 32)
+            break;
         default: return THR_ERR_UNSUPPORTED;
     }
 #undef THR_Q_LAUNCH
@@ -1729,7 +1743,7 @@ extern "C" int thr_dense_f16_max_queries(int dim, int packed) {
 extern "C" int thr_dense_f16_query_tile(int dim, int packed, int n_queries) {
     if (dim != 512 && dim != 768 && dim != 1024) return 0;
     (void)n_queries;
-    return packed ? 32 * qreg_waves(dim) : 32 * f16_pick_nq(dim);
+    return packed ? qreg_qw(dim) * qreg_waves(dim) : 32 * f16_pick_nq(dim);
 }
 
 extern "C" size_t thr_dense_f16_copy_bytes(int64_t n_docs, int dim) {

@@ -56,6 +56,12 @@ struct QScan {
     static constexpr int PER_CU = DIM <= 768 ? 2 : 1;   // blocks per CU (256 B-operand VGPRs at 1024)
     static constexpr int NB = (160 * 1024 / PER_CU) / HALF_BYTES > 4 ? 4 : (160 * 1024 / PER_CU) / HALF_BYTES;
     static constexpr int PER = HS / Q_NW;           // pieces a wave issues per half tile
+#ifndef THR_Q_RING_1024
+#define THR_Q_RING_1024 8
+#endif
+    // A fragments in flight per wave: a block that is alone on its CU (dim 1024) has one wave per
+    // SIMD, nobody else's MFMAs cover an LDS read that returns late
+    static constexpr int RING = PER_CU == 1 ? THR_Q_RING_1024 : Q_RING;
     static constexpr int LDS_BYTES = NB * HALF_BYTES;
     static_assert(HS % Q_NW == 0 && NB >= 3, "half tile must split evenly over the waves; >= 3 buffers");
 };
@@ -156,9 +162,9 @@ __global__ __launch_bounds__(256) void pack_queries_f16(const float* __restrict_
 // asm operands do not capture.)
 #define QS_RD(dst, ks) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(abase), "n"((ks) * 1024) : "memory")
-template <int S, int HS>
-__device__ __forceinline__ void qs_fill(f32x4 (&a)[Q_RING], uint32_t abase) {
-    if constexpr (S < Q_RING && S < HS) {
+template <int S, int HS, int RING>
+__device__ __forceinline__ void qs_fill(f32x4 (&a)[RING], uint32_t abase) {
+    if constexpr (S < RING && S < HS) {
         QS_RD(a[S], S);
         qs_fill<S + 1, HS>(a, abase);
     }
@@ -172,9 +178,15 @@ __device__ __forceinline__ void qs_fill(f32x4 (&a)[Q_RING], uint32_t abase) {
 // The accumulators are 16 registers either way; QAcc maps register x to (row, query half).
 template <int SHAPE>
 struct QAcc;
+// SHAPE = 48 (round 4, dim 1024): the 16x16x32 MFMA against THREE 16-query blocks -- 48 queries
+//             per wave, 192 per CU: three MFMAs per LDS fragment, and every row tile that is
+//             brought into LDS serves half again as many queries (the query image is a sequence of
+//             16-query blocks either way: block B's fragments sit at [B * KS/2 + k32]).
+// QW = queries per wave, NQB = 16-query blocks, NREG = accumulator registers.
 template <>
 struct QAcc<32> {
     static constexpr int NQL = 1, SEGS = 2;   // queries per lane; candidate segments per row slice
+    static constexpr int QW = 32, NQB = 2, NREG = 16;
     f32x16 v;
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -188,8 +200,26 @@ struct QAcc<32> {
     static __device__ __forceinline__ int seg(int lane) { return lane >> 5; }
 };
 template <>
+struct QAcc<48> {
+    static constexpr int NQL = 3, SEGS = 4;
+    static constexpr int QW = 48, NQB = 3, NREG = 24;
+    f32x4 t[6];   // tile [row half ra][query block qb] at 3 ra + qb
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int x = 0; x < 6; ++x) t[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    template <int X> __device__ __forceinline__ float get() const { return t[X >> 2][X & 3]; }
+    // lane (c = lane & 15, g = lane >> 4): register x = 4 (3 ra + qb) + j is row 16 ra + 4 g + j
+    // of query 16 qb + c
+    template <int X> static __device__ __forceinline__ int row(int lane) { return 16 * ((X >> 2) / 3) + 4 * (lane >> 4) + (X & 3); }
+    template <int X> static constexpr int qsel() { return (X >> 2) % 3; }
+    static __device__ __forceinline__ int query(int lane, int qb) { return 16 * qb + (lane & 15); }
+    static __device__ __forceinline__ int seg(int lane) { return lane >> 4; }
+};
+template <>
 struct QAcc<16> {
     static constexpr int NQL = 2, SEGS = 4;
+    static constexpr int QW = 32, NQB = 2, NREG = 16;
     f32x4 t[4];   // tile [row half ra][query half qb] at 2 ra + qb
     __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -206,27 +236,33 @@ struct QAcc<16> {
 
 // piece S of a half tile (HS pieces): SHAPE 32 -> k-step K0 + S; SHAPE 16 -> row half S & 1 of
 // k32-step (K0 + S) / 2, B operands bq[qb * KS/2 + k32]
-template <int S, int HS, int K0, int KS, int PER, int SHAPE, typename Issue>
-__device__ __forceinline__ void qsx_steps(f32x4 (&a)[Q_RING], const f32x4 (&bq)[KS], QAcc<SHAPE>& acc,
+// the MFMAs of piece S: SHAPE 32 one, else one per 16-query block of the wave
+template <int S, int K0, int KS, int SHAPE, int NBQ>
+__device__ __forceinline__ void qsx_mfma(const f32x4& a, const f32x4 (&bq)[NBQ], QAcc<SHAPE>& acc) {
+    if constexpr (SHAPE == 32) {
+        acc.v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a),
+                                                       __builtin_bit_cast(half8, bq[K0 + S]), acc.v, 0, 0, 0);
+    } else {
+        constexpr int k32 = (K0 + S) / 2, ra = S & 1, NQB = QAcc<SHAPE>::NQB;
+        static_assert(NBQ == NQB * KS / 2, "one B fragment per 16-query block and 32-dim step");
+        static_for<0, NQB>([&](auto qb) {
+            acc.t[NQB * ra + qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                __builtin_bit_cast(half8, a), __builtin_bit_cast(half8, bq[qb * (KS / 2) + k32]),
+                acc.t[NQB * ra + qb], 0, 0, 0);
+        });
+    }
+}
+template <int S, int HS, int K0, int KS, int PER, int SHAPE, int RING, int NBQ, typename Issue>
+__device__ __forceinline__ void qsx_steps(f32x4 (&a)[RING], const f32x4 (&bq)[NBQ], QAcc<SHAPE>& acc,
                                           uint32_t abase, Issue& issue_piece) {
     if constexpr (S < HS) {
-        constexpr int left = HS - S - 1 < Q_RING - 1 ? HS - S - 1 : Q_RING - 1;
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % Q_RING]) : "n"(left) : "memory");
-        if constexpr (SHAPE == 32) {
-            acc.v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[S % Q_RING]),
-                                                           __builtin_bit_cast(half8, bq[K0 + S]), acc.v, 0, 0, 0);
-        } else {
-            constexpr int k32 = (K0 + S) / 2, ra = S & 1;
-            acc.t[2 * ra] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[k32]), acc.t[2 * ra], 0, 0, 0);
-            acc.t[2 * ra + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[KS / 2 + k32]),
-                acc.t[2 * ra + 1], 0, 0, 0);
-        }
-        if constexpr (S + Q_RING < HS) QS_RD(a[S % Q_RING], S + Q_RING);
+        constexpr int left = HS - S - 1 < RING - 1 ? HS - S - 1 : RING - 1;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % RING]) : "n"(left) : "memory");
+        qsx_mfma<S, K0, KS, SHAPE>(a[S % RING], bq, acc);
+        if constexpr (S + RING < HS) QS_RD(a[S % RING], S + RING);
         constexpr int every = HS / PER;
         if constexpr (S % every == 1 && S / every < PER) issue_piece(std::integral_constant<int, S / every>{});
-        qsx_steps<S + 1, HS, K0, KS, PER, SHAPE>(a, bq, acc, abase, issue_piece);
+        qsx_steps<S + 1, HS, K0, KS, PER, SHAPE, RING, NBQ>(a, bq, acc, abase, issue_piece);
     }
 }
 
@@ -260,7 +296,7 @@ struct QEmit {
     }
     template <int X>
     __device__ __forceinline__ void all(const QAcc<SHAPE>& acc, uint32_t row0, int lane) {
-        if constexpr (X < 16) {
+        if constexpr (X < QAcc<SHAPE>::NREG) {
             one<X>(acc, row0, lane);
             all<X + 1>(acc, row0, lane);
         }
@@ -273,30 +309,22 @@ struct QEmit {
 // tile.  Here the 16 accumulator registers of tile i - 1 are compared / stored one at a time
 // between the MFMAs of tile i (8 per half tile, evenly spaced): an MFMA occupies the pipe for
 // 16 cycles after it issues, which is what one register's compare-and-branch takes to issue.
-template <int S, int HS, int K0, int KS, int PER, int SHAPE, int HF, typename Issue>
-__device__ __forceinline__ void qsx_steps_pe(f32x4 (&a)[Q_RING], const f32x4 (&bq)[KS], QAcc<SHAPE>& acc,
+template <int S, int HS, int K0, int KS, int PER, int SHAPE, int HF, int RING, int NBQ, typename Issue>
+__device__ __forceinline__ void qsx_steps_pe(f32x4 (&a)[RING], const f32x4 (&bq)[NBQ], QAcc<SHAPE>& acc,
                                              uint32_t abase, Issue& issue_piece, QEmit<SHAPE>& em,
                                              const QAcc<SHAPE>& prv, uint32_t row_prv, int lane) {
     if constexpr (S < HS) {
-        constexpr int left = HS - S - 1 < Q_RING - 1 ? HS - S - 1 : Q_RING - 1;
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % Q_RING]) : "n"(left) : "memory");
-        if constexpr (SHAPE == 32) {
-            acc.v = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[S % Q_RING]),
-                                                           __builtin_bit_cast(half8, bq[K0 + S]), acc.v, 0, 0, 0);
-        } else {
-            constexpr int k32 = (K0 + S) / 2, ra = S & 1;
-            acc.t[2 * ra] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[k32]), acc.t[2 * ra], 0, 0, 0);
-            acc.t[2 * ra + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                __builtin_bit_cast(half8, a[S % Q_RING]), __builtin_bit_cast(half8, bq[KS / 2 + k32]),
-                acc.t[2 * ra + 1], 0, 0, 0);
-        }
-        if constexpr (S + Q_RING < HS) QS_RD(a[S % Q_RING], S + Q_RING);
+        constexpr int left = HS - S - 1 < RING - 1 ? HS - S - 1 : RING - 1;
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[S % RING]) : "n"(left) : "memory");
+        qsx_mfma<S, K0, KS, SHAPE>(a[S % RING], bq, acc);
+        if constexpr (S + RING < HS) QS_RD(a[S % RING], S + RING);
         constexpr int every = HS / PER;
         if constexpr (S % every == 1 && S / every < PER) issue_piece(std::integral_constant<int, S / every>{});
-        constexpr int ev_e = HS / 8;   // (HS is 8, 12 or 16 k-steps times the pieces per step: a multiple of 8)
-        if constexpr (S % ev_e == ev_e - 1 && S / ev_e < 8) em.template one<8 * HF + S / ev_e>(prv, row_prv, lane);
-        qsx_steps_pe<S + 1, HS, K0, KS, PER, SHAPE, HF>(a, bq, acc, abase, issue_piece, em, prv, row_prv, lane);
+        // half the registers of the previous tile per half tile, evenly spaced: register j after the
+        // step at which j = floor(S * NRH / HS) is about to change
+        constexpr int NRH = QAcc<SHAPE>::NREG / 2, j = S * NRH / HS;
+        if constexpr ((S + 1) * NRH / HS > j) em.template one<NRH * HF + j>(prv, row_prv, lane);
+        qsx_steps_pe<S + 1, HS, K0, KS, PER, SHAPE, HF, RING, NBQ>(a, bq, acc, abase, issue_piece, em, prv, row_prv, lane);
     }
 }
 #undef QS_RD
@@ -316,20 +344,21 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     unsigned long long* __restrict__ stamps = nullptr) {
     using C = QScan<DIM>;
     using A = QAcc<SHAPE>;
-    constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER, NQL = A::NQL;
+    constexpr int KS = C::KS, HS = C::HS, NB = C::NB, PER = C::PER, NQL = A::NQL, QW = A::QW;
+    constexpr int NBQ = SHAPE == 32 ? KS : A::NQB * KS / 2;   // B fragments of the wave's queries
     extern __shared__ f32x4 lds_rows[];  // NB half-tile buffers
 
     const ScanSlot slot = scan_slot(n_qtiles);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q32 = slot.qtile * Q_NW + wave;  // this wave's tile of 32 queries
-    const bool idle = (int64_t)q32 * 32 >= n_queries;   // all padding: only moves row pieces
+    const int q32 = slot.qtile * Q_NW + wave;  // this wave's tile of QW (32, or 48) queries
+    const bool idle = (int64_t)q32 * QW >= n_queries;   // all padding: only moves row pieces
 
     // B operands: the wave's 32 queries, all k-steps, in registers for the whole launch
-    f32x4 bq[KS];
+    f32x4 bq[NBQ];
     if (!idle)
-        static_for<0, KS>([&](auto s) {
-            bq[s] = qfrag[((int64_t)q32 * KS + s) * 64 + lane];
+        static_for<0, NBQ>([&](auto s) {
+            bq[s] = qfrag[((int64_t)q32 * NBQ + s) * 64 + lane];
         });
     // the lane's private candidate segments (MODE_FILTER): query q, segment SEGS * slice + seg(lane)
     const int nseg = A::SEGS * slot.nslices;
@@ -340,7 +369,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     uint32_t start[NQL];
 #pragma unroll
     for (int u = 0; u < NQL; ++u) {
-        const int q = q32 * 32 + A::query(lane, u);
+        const int q = q32 * QW + A::query(lane, u);
         em.tau[u] = MODE == MODE_FILTER ? tau[q] : 0.f;
         // collection filter of this lane's query (-1: none): checked only for rows that pass tau
         em.qc[u] = (MODE == MODE_FILTER && query_coll && q < n_queries) ? query_coll[q] : -1;
@@ -415,10 +444,11 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     // (Only where a block is alone on its CU -- dim 1024, one wave per SIMD: with two blocks per CU
     // the other block's MFMAs already cover an epilogue, and the second accumulator set does not fit
     // the 256-register budget there.)
-    if constexpr (MODE == MODE_FILTER && !PROF && C::PER_CU == 1) {
+    // (And not with 48 queries per wave: 384 B-operand registers leave no room for a second set.)
+    if constexpr (MODE == MODE_FILTER && !PROF && C::PER_CU == 1 && SHAPE != 48) {
         A acc2[2];
 #pragma unroll
-        for (int x = 0; x < 16; ++x) {
+        for (int x = 0; x < A::NREG; ++x) {
             if constexpr (SHAPE == 32) acc2[1].v[x] = -INFINITY;
             else acc2[1].t[x >> 2][x & 3] = -INFINITY;
         }
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
         auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
         const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
-        f32x4 a[Q_RING];                                                                           \
+        f32x4 a[C::RING];                                                                           \
         qs_fill<0, HS>(a, abase);                                                                  \
         qsx_steps_pe<0, HS, (hf) * HS, KS, PER, SHAPE, (hf)>(a, bq, acc2[CUR], abase, issue_piece, \
                                                             em, acc2[PRV], row_of[PRV], lane);     \
@@ -479,13 +509,16 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
         auto issue_piece = [&](auto P) { dma(src, nbuf, decltype(P)::value); };                    \
         const uint32_t abase = lds_base + buf * C::HALF_BYTES + lane * 16;                         \
-        f32x4 a[Q_RING];                                                                           \
+        f32x4 a[C::RING];                                                                           \
         qs_fill<0, HS>(a, abase);                                                                  \
         stamp(2);                                                                                  \
         qsx_steps<0, HS, (hf) * HS, KS, PER, SHAPE>(a, bq, acc, abase, issue_piece);                \
         if constexpr (PROF) {                                                                      \
             if constexpr (SHAPE == 32) asm volatile("" : "+v"(acc.v));                               \
-            else asm volatile("" : "+v"(acc.t[0]), "+v"(acc.t[1]), "+v"(acc.t[2]), "+v"(acc.t[3])); \
+            else {                                                                                 \
+                asm volatile("" : "+v"(acc.t[0]), "+v"(acc.t[1]), "+v"(acc.t[2]), "+v"(acc.t[3]));   \
+                if constexpr (A::NQB == 3) asm volatile("" : "+v"(acc.t[4]), "+v"(acc.t[5]));       \
+            }                                                                                      \
         }                                                                                          \
         stamp(3);                                                                                  \
         buf = buf + 1 == NB ? 0 : buf + 1;                                                         \
@@ -512,12 +545,12 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
                 }
             } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {   // tile (ra, qb): rows 16 ra + 4 g .. + 4 of query 16 qb + c
+                for (int x = 0; x < 2 * A::NQB; ++x) {   // tile (ra, qb): rows 16 ra + 4 g .. + 4 of query 16 qb + c
                     f32x4 v = acc.t[x];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] == v[j] ? v[j] : -INFINITY;
-                    float* dst = sample_scores + (int64_t)(q32 * 32 + 16 * (x & 1) + (lane & 15)) * sample_ld +
-                                 t * 32 + 16 * (x >> 1) + 4 * (lane >> 4);
+                    float* dst = sample_scores + (int64_t)(q32 * QW + 16 * (x % A::NQB) + (lane & 15)) * sample_ld +
+                                 t * 32 + 16 * (x / A::NQB) + 4 * (lane >> 4);
                     *reinterpret_cast<f32x4*>(dst) = v;
                 }
             }
@@ -532,7 +565,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     if constexpr (MODE == MODE_FILTER) {
 #pragma unroll
         for (int u = 0; u < NQL; ++u)
-            seg_cnt[(int64_t)(q32 * 32 + A::query(lane, u)) * nseg + my_seg] = (int)((em.slot[u] - start[u]) / sizeof(Cand));
+            seg_cnt[(int64_t)(q32 * QW + A::query(lane, u)) * nseg + my_seg] = (int)((em.slot[u] - start[u]) / sizeof(Cand));
     }
     if constexpr (PROF) {
         if (lane == 0) {
