@@ -62,7 +62,11 @@ struct QScan {
     // A fragments in flight per wave: a block that is alone on its CU (dim 1024) has one wave per
     // SIMD, nobody else's MFMAs cover an LDS read that returns late
     static constexpr int RING = PER_CU == 1 ? THR_Q_RING_1024 : Q_RING;
-    static constexpr int LDS_BYTES = NB * HALF_BYTES;
+#ifdef Q_PROBE_EXTRA
+    static constexpr int VM_PER_PIECE = 2, LDS_BYTES = NB * HALF_BYTES + 32 * 1024;   // (diagnostic: dma())
+#else
+    static constexpr int VM_PER_PIECE = 1, LDS_BYTES = NB * HALF_BYTES;
+#endif
     static_assert(HS % Q_NW == 0 && NB >= 3, "half tile must split evenly over the waves; >= 3 buffers");
 };
 
@@ -395,12 +399,33 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         const int64_t t = first + (jc >> 1) * step;
         return packed + ((t * tile_stride * KS + (jc & 1) * HS + wave) * 64 + lane);
     };
+#ifdef Q_PROBE_EXTRA
+    f32x4 probe_reg = {0.f, 0.f, 0.f, 0.f};   // (diagnostic builds only: see below)
+#endif
     auto dma = [&](const f32x4* src, int buf, int p) {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + p * Q_NW * 64),
             (__attribute__((address_space(3))) void*)(size_t)(lds_base + buf * C::HALF_BYTES +
                                                               (wave + p * Q_NW) * 1024),
             16, 0, 0);
+#ifdef Q_PROBE_EXTRA
+        // Diagnostic builds (_build.build_variant(name, ["Q_PROBE_EXTRA=1|2"]), dim 1024): is the
+        // wave's instruction issue what bounds the k-loop?  Every row piece is issued a SECOND time
+        // into 32 KiB of LDS nobody reads -- 1: as another LDS-DMA piece, 2: as a plain load into a
+        // register plus a ds_write_b128 of that register (stale data: only the issue slots
+        // matter).  Results are unchanged.  Measured (scripts/probe_dim1024.py 1000000 2048, one
+        // box): 4.201 ms as shipped, 4.180 with the pieces doubled, 4.160 with the load + write
+        // added -- the extra instructions are free: not issue-bound.
+        const uint32_t scratch = lds_base + NB * C::HALF_BYTES + (wave + (p & 7) * Q_NW) * 1024;
+        if constexpr (Q_PROBE_EXTRA == 1) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + p * Q_NW * 64),
+                (__attribute__((address_space(3))) void*)(size_t)scratch, 16, 0, 0);
+        } else {
+            asm volatile("ds_write_b128 %0, %1" ::"v"(scratch + lane * 16), "v"(probe_reg) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(probe_reg) : "v"(src + p * Q_NW * 64) : "memory");
+        }
+#endif
     };
     if (n_half > 0) {
 #pragma unroll
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         // MFMAs, nothing to emit (see dense_scan_f16qs below)
 #pragma unroll 1
         for (int64_t j = 0; j < n_half; ++j) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER * C::VM_PER_PIECE) : "memory");
             __builtin_amdgcn_s_barrier();
             const int nbuf = buf == 0 ? NB - 1 : buf - 1;
             const f32x4* src = piece_src(j + NB - 1);
@@ -455,7 +480,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         uint32_t row_of[2] = {0u, 0u};
 #define QS_HALF_PE(hf, CUR, PRV)                                                                   \
     {                                                                                              \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER * C::VM_PER_PIECE) : "memory");                      \
         __builtin_amdgcn_s_barrier();                                                              \
         const int nbuf = buf == 0 ? NB - 1 : buf - 1; /* half tile j-1's buffer */                 \
         const f32x4* src = piece_src(2 * i + (hf) + NB - 1);                                       \
@@ -501,7 +526,7 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         stamp(-1);                                                                                 \
         /* own pieces of half tile 2i+hf done (the NB-2 younger half tiles' pieces -- and the      \
            emit's few stores among them, which are over-waited for -- may stay in flight) */       \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER) : "memory");                      \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER * C::VM_PER_PIECE) : "memory");                      \
         stamp(0);                                                                                  \
         __builtin_amdgcn_s_barrier();                                                              \
         stamp(1);                                                                                  \
