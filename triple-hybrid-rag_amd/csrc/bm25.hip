@@ -1481,6 +1481,7 @@ __global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
     const double* __restrict__ idf, const double* __restrict__ term_ub,
     const uint8_t* __restrict__ post_imp, const int32_t* __restrict__ dense_slot,
     const uint16_t* __restrict__ dense_tf, int64_t dense_stride, double avgdl, double k1, double b,
+    double imp_unit /* (k1 + 1) / 255 */, double imp_per_unit /* 255 / (k1 + 1): the host's divisions, same bits */,
     int64_t id_base, int max_terms, int k, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int32_t* __restrict__ ctl,
     const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
@@ -1542,7 +1543,7 @@ __global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
             const double ubt = tr_.ub;
             const int64_t row_l = tr_.row;
             // integer weights of the quantised impacts, as bm25_topk_kernel computes them
-            const double c = (k1 + 1.0) / 255.0;
+            const double c = imp_unit;
             double sum = idf_l * c;
 #pragma unroll
             for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);   // (lanes 0..7 hold the terms; 8.. hold zeros)
@@ -1551,7 +1552,7 @@ __global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
             w = on && w < 1 ? 1 : w;
             // the probed terms' largest quantised impacts in accumulator units (their bound / idf in
             // steps of (k1+1)/255, as bm25_bounds_kernel rounds)
-            const double im = probed ? (idf_l > 0.0 ? ceil(ubt / idf_l * (255.0 / (k1 + 1.0))) + 1.0 : 255.0) : 0.0;
+            const double im = probed ? (idf_l > 0.0 ? ceil(ubt / idf_l * imp_per_unit) + 1.0 : 255.0) : 0.0;
             dm_l = probed ? w * (im > 255.0 || !(im >= 0.0) ? 255 : (int)im) : 0;
 #pragma unroll
             for (int o = 4; o > 0; o >>= 1) dm_l += __shfl_xor(dm_l, o, WAVE);
@@ -1830,19 +1831,23 @@ __global__ __launch_bounds__(WW_WAVES * 64, 4) void bm25_walk_wave_kernel(
         ww_sync();
         ww_sort(L.b_s, L.b_id, lane);
         const int n = b_cnt < k ? b_cnt : k;
+        // (the output addresses are formed HERE: formed at the top of the item, as the compiler
+        // would, they are four registers carried -- spilled -- through the whole walk)
+        int q_w = __builtin_amdgcn_readfirstlane(q), item_w = __builtin_amdgcn_readfirstlane(item);
+        asm volatile("" : "+s"(q_w), "+s"(item_w));
         if (S == 1) {   // the query's only item: its list is the result
             for (int i = lane; i < k; i += 64) {
-                out_s[(int64_t)q * k + i] = i < n ? L.b_s[i] : -INFINITY;
-                out_id[(int64_t)q * k + i] = i < n ? (int64_t)L.b_id[i] + id_base : -1;
+                out_s[(int64_t)q_w * k + i] = i < n ? L.b_s[i] : -INFINITY;
+                out_id[(int64_t)q_w * k + i] = i < n ? (int64_t)L.b_id[i] + id_base : -1;
             }
-            if (lane == 0) out_cnt[q] = n;
+            if (lane == 0) out_cnt[q_w] = n;
         } else {
             for (int i = lane; i < n; i += 64) {
-                slice_s[(int64_t)item * k + i] = L.b_s[i];
-                slice_id[(int64_t)item * k + i] = (int64_t)L.b_id[i] + id_base;
+                slice_s[(int64_t)item_w * k + i] = L.b_s[i];
+                slice_id[(int64_t)item_w * k + i] = (int64_t)L.b_id[i] + id_base;
             }
             if (lane == 0) {
-                slice_cnt[item] = n;
+                slice_cnt[item_w] = n;
                 if (n >= k) atomicMax(&theta_glob[q], (unsigned long long)dkey(L.b_s[k - 1]));
             }
         }
@@ -2609,6 +2614,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
         if ((long long)n_queries * 32 + 32 < wgrid_w) wgrid_w = n_queries * 32 + 32;
         hipLaunchKernelGGL(bm25_walk_wave_kernel, dim3(wgrid_w), dim3(WW_WAVES * 64), 0, st, rowptr, post_doc,
                            post_tf, doclen, idf, term_ub, post_imp, dslot, dense_tf, dense_stride, avgdl, k1, b,
+                           (k1 + 1.0) / 255.0, 255.0 / (k1 + 1.0),
                            id_base, max_terms, k, doc_coll, query_coll, ctl, q_nt, q_S, q_SA, q_pmask, q_terms,
                            items, ipos, wrec, wterm, theta, slice_s, slice_id, slice_cnt, out_scores, out_ids, out_counts
 #ifdef BM_STAMPS

@@ -470,7 +470,12 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
     // the other block's MFMAs already cover an epilogue, and the second accumulator set does not fit
     // the 256-register budget there.)
     // (And not with 48 queries per wave: 384 B-operand registers leave no room for a second set.)
-    if constexpr (MODE == MODE_FILTER && !PROF && C::PER_CU == 1 && SHAPE != 48) {
+#ifdef Q_NO_PIPE_EMIT   // (A/B builds: the round-3 loop, the emit after its own tile)
+    constexpr bool PIPE_EMIT = false;
+#else
+    constexpr bool PIPE_EMIT = true;
+#endif
+    if constexpr (PIPE_EMIT && MODE == MODE_FILTER && !PROF && C::PER_CU == 1 && SHAPE != 48) {
         A acc2[2];
 #pragma unroll
         for (int x = 0; x < A::NREG; ++x) {
