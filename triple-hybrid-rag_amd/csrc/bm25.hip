@@ -582,7 +582,9 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
     const double* __restrict__ idf, const double* __restrict__ term_ub,
     const double* __restrict__ block_ub, const uint8_t* __restrict__ post_imp,
     const int32_t* __restrict__ dense_slot, const uint16_t* __restrict__ dense_tf, int64_t dense_stride,
-    double avgdl, double k1, double b, int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
+    double avgdl, double k1, double b,
+    double imp_unit /* (k1 + 1) / 255 */, double imp_per_unit /* 255 / (k1 + 1): the host's divisions, same bits */,
+    int64_t id_base, int max_terms, int k, int conjunctive, const int32_t* __restrict__ doc_coll,
     const int32_t* __restrict__ query_coll, int n_queries, int fuse_div, int32_t* __restrict__ ctl,
     const int32_t* __restrict__ q_nt, const int32_t* __restrict__ q_S, const int32_t* __restrict__ q_SA,
     const int32_t* __restrict__ q_pmask,
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                 t_order[c] = ta;
             }
             if (acc_ok) {
-                const double c = (k1 + 1.0) / 255.0;
+                const double c = imp_unit;
                 double sum = 0.0;
                 for (int t = 0; t < nt; ++t) sum += t_idf[t] * c;
                 const double scale = 248.0 / sum;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(BM_THREADS, 4) void bm25_topk_kernel(
                     if (t_row[t] < 0) continue;
                     dub += t_ub[t];
                     // the term's largest quantised impact: its bound / idf in steps of (k1+1)/255, as bm25_bounds_kernel rounds
-                    const double im = t_idf[t] > 0.0 ? ceil(t_ub[t] / t_idf[t] * (255.0 / (k1 + 1.0))) + 1.0 : 255.0;
+                    const double im = t_idf[t] > 0.0 ? ceil(t_ub[t] / t_idf[t] * imp_per_unit) + 1.0 : 255.0;
                     dmaxq += t_w[t] * (im > 255.0 || !(im >= 0.0) ? 255 : (int)im);
                 }
                 p_dub = dub;
@@ -2594,7 +2596,7 @@ extern "C" int thr_bm25_topk(const int64_t* rowptr, const int32_t* post_doc, con
     hipLaunchKernelGGL((bm25_topk_kernel<T, S, W, C, DP>), dim3(grid), dim3(T), 0, st, rowptr, post_doc, \
                        post_tf, doclen, idf, term_ub, term_ub ? block_ub : nullptr,                 \
                        term_ub ? post_imp : nullptr, dslot, dense_tf, dense_stride,    \
-                       avgdl, k1, b,                                                                \
+                       avgdl, k1, b, (k1 + 1.0) / 255.0, 255.0 / (k1 + 1.0),                        \
                        id_base, max_terms, k, conjunctive, doc_coll, query_coll, n_queries,         \
                        wave ? -1 : dslot ? fuse_div : 0, ctl, q_nt, q_S,                            \
                        q_SA, q_pmask, q_terms, items, ipos, theta, slice_s, slice_id, slice_cnt,    \
