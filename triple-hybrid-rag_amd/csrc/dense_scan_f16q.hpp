@@ -413,9 +413,9 @@ __global__ __launch_bounds__(Q_NW * 64, QScan<DIM>::PER_CU) void dense_scan_f16q
         // wave's instruction issue what bounds the k-loop?  Every row piece is issued a SECOND time
         // into 32 KiB of LDS nobody reads -- 1: as another LDS-DMA piece, 2: as a plain load into a
         // register plus a ds_write_b128 of that register (stale data: only the issue slots
-        // matter).  Results are unchanged.  Measured (scripts/probe_dim1024.py 1000000 2048, one
-        // box): 4.201 ms as shipped, 4.180 with the pieces doubled, 4.160 with the load + write
-        // added -- the extra instructions are free: not issue-bound.
+        // matter).  Results are unchanged.  Measured (THR_DENSE_QW=32 scripts/probe_dim1024.py
+        // 1000000 2048, one box): 4.201 ms plain, 4.180 with the pieces doubled, 4.160 with the load
+        // + write added -- the extra instructions are free: not issue-bound.
         const uint32_t scratch = lds_base + NB * C::HALF_BYTES + (wave + (p & 7) * Q_NW) * 1024;
         if constexpr (Q_PROBE_EXTRA == 1) {
             __builtin_amdgcn_global_load_lds(
