@@ -284,12 +284,13 @@ def test_bm25_matches_oracle(T):
     assert int(cnt[3]) == 0
 
 
-@pytest.mark.parametrize("knob", ["THR_DENSE_MFMA=32", "THR_DENSE_F16=q"])
+@pytest.mark.parametrize("knob", ["THR_DENSE_MFMA=32", "THR_DENSE_F16=q", "THR_DENSE_QW=32"])
 def test_dense_alternate_scan_builds_in_a_subprocess(knob):
     """The documented A/B knobs of the default scan are read once per process:
     THR_DENSE_MFMA=32 (the 32x32x16 build of the staggered kernel, with its own copy / query
-    image layouts) and THR_DENSE_F16=q (the two-blocks-per-CU kernel at dim <= 768).  The f16
-    parity tests run again under each."""
+    image layouts), THR_DENSE_F16=q (the two-blocks-per-CU kernel at dim <= 768) and
+    THR_DENSE_QW=32 (dim 1024 with 32 queries per wave and the emit threaded through the next
+    tile's MFMAs, instead of 48 per wave).  The f16 parity tests run again under each."""
     import os
     import subprocess
     import sys
