@@ -150,3 +150,59 @@ def test_rerank_exchange_second_all_gather(tmp_path):
     assert np.array_equal(merged, full.astype(np.float32))
     for q in range(4):
         assert O.rerank_order(list(merged[q])) == O.rerank_order(list(full[q].astype(np.float32)))
+
+
+def _worker_floor_agreement(rank, world, port, out_dir):
+    import os
+    import sys
+    import types
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from triple_hybrid_rag_amd.distributed import ShardedIndex
+    from triple_hybrid_rag_amd.index import floor_width
+    out = {}
+    # every shard on an f16 scan: the floor is on, and the exchange hands back all the shards' tiles
+    sh = ShardedIndex(types.SimpleNamespace(shortlist="f16", device=torch.device("cpu")))
+    out["all_f16"] = sh.floor and sh._floor_exchange() is not None
+    fx, g = sh._floor_exchange()
+    lb = torch.full((5, floor_width(100, world)), float(rank), dtype=torch.float32)
+    got = fx(lb)
+    out["tiles"] = list(got.shape) == [world, 5, floor_width(100, world)] and \
+        all(bool(torch.all(got[r] == float(r))) for r in range(world)) and g == world
+    # ONE shard fell back to the float32 scan (rows outside the float16 range): nobody uses the
+    # floor -- a rank that skipped the exchange while the others entered it would hang the group
+    sh = ShardedIndex(types.SimpleNamespace(shortlist="f32" if rank == 1 else "f16", device=torch.device("cpu")))
+    out["one_f32"] = (not sh.floor) and sh._floor_exchange() is None
+    # switched off by the caller: no collective at construction either
+    sh = ShardedIndex(types.SimpleNamespace(shortlist="f16", device=torch.device("cpu")), floor=False)
+    out["off"] = sh._floor_exchange() is None
+    import json
+    with open(os.path.join(out_dir, f"floor_{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shards_agree_on_the_floor_exchange(tmp_path):
+    """ShardedIndex splits the dense channel around one more all-gather only if EVERY shard of the
+    group can (the scan a shard runs depends on its own rows): decided once, collectively."""
+    import json
+    world = 3
+    port = 29500 + os.getpid() % 1000 + 7
+    mp.spawn(_worker_floor_agreement, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = json.load(open(tmp_path / f"floor_{r}.json"))
+        assert got == {"all_f16": True, "tiles": True, "one_f32": True, "off": True}, (r, got)
+
+
+def test_floor_width():
+    from triple_hybrid_rag_amd.index import floor_width
+    assert floor_width(100, 8) == 26 and floor_width(100, 2) == 100 and floor_width(10, 8) == 16
+    assert floor_width(256, 1) == 256                       # never above THR_DENSE_MAX_K
+    for g in (1, 2, 3, 8, 64, 256, 1000):
+        for k in (1, 10, 100, 256):
+            m = floor_width(k, g)
+            assert 1 <= m <= 256 and g * m <= max(4096, g)  # the band kernel's LDS holds the G * m values

@@ -157,6 +157,8 @@ class ShardedIndex:
     def _floor_exchange(self):
         if self.world == 1 or not self.floor or self.local.shortlist not in ("f16", "f16-inline"):
             return None
+        if self.world > 4096:   # (the band kernel holds the shards' G * m bounds in 4096 LDS words)
+            return None
         return (lambda lb: gather_rows(lb, self.group)), self.world
 
     def _merge(self, S, I, k):
